@@ -1,0 +1,153 @@
+"""Known-answer vectors restated from the reference's own tests (data only; citations give file:line
+under the reference checkout).  They pin oracle/wc_oracle.py independently of tools/gen_golden.py."""
+import numpy as np
+import pytest
+
+from oracle import wc_oracle as O
+
+EPS = np.float32(2 ** -23)
+
+# tests/openvino/native/quantization/test_weights_compression.py:2226-2243
+E2M1_EDGE = [(-7.0, -6.0), (7.0, 6.0), (-5.0, -4.0), (-3.5, -4.0), (1.75, 2.0), (2.5, 2.0), (-4.0, -4.0),
+             (0.0, 0.0), (-0.0, 0.0), (-0.25, 0.0), (0.25, 0.0), (-0.49, -0.5), (-0.51, -0.5)]
+
+
+@pytest.mark.parametrize("x,expected", E2M1_EDGE)
+def test_mxfp4_edge_cases(x, expected):
+    got = O.calculate_float_quantized_weight(np.array([x], np.float32), "mxfp4")
+    assert got[0] == expected
+
+
+def test_e2m1_rule_is_rne_on_dense_grid():
+    # the reference tie rule equals IEEE round-to-nearest-even on the e2m1 grid, saturating at +-6
+    x = np.linspace(-8, 8, 64001).astype(np.float32)
+    got = O.calculate_float_quantized_weight(x, "mxfp4")
+    grid = np.array([0, .5, 1, 1.5, 2, 3, 4, 6], np.float32)
+    even = np.array([1, 0, 1, 0, 1, 0, 1, 0], bool)
+    a = np.abs(x)
+    d = np.abs(a[:, None] - grid[None])
+    best = d.min(1, keepdims=True)
+    cand = d == best
+    pick = np.where(cand.sum(1) > 1, np.argmax(cand & even[None], 1), np.argmax(cand, 1))
+    exp = np.sign(x) * grid[pick]
+    assert np.array_equal(np.abs(got), np.abs(exp)) and np.all((got == exp))
+
+
+def test_nf4_mid_quant():
+    # test_weights_compression.py:2210-2223: norm weight one ulp above the first NF4 center -> 2nd quantile
+    w = np.array([-0.07263] * 2, np.float16).astype(np.float32)
+    s = np.array([0.08564102] * 2, np.float32)
+    got = O.calculate_float_quantized_weight(w / s, "nf4")
+    assert np.all(got == O.NF4_QUANTILES[1])
+
+
+# SURVEY Appendix A11 (probed on the reference; numpy == torch), INT4, group size 8
+DEGENERATE = [
+    (np.zeros(8), [0] * 8, EPS, 0, [0] * 8, EPS),
+    (np.full(8, .5), [15] * 8, EPS, 0, [7] * 8, 0.0625),
+    (np.full(8, -.5), [0] * 8, EPS, 15, [-8] * 8, 0.0625),
+    (np.full(8, -300.), [0] * 8, EPS, 0, [-8] * 8, 37.5),
+    ([-7.5, -6.5, -.5, .5, 1.5, 2.5, 6.5, 7.5], [0, 2, 8, 8, 10, 10, 14, 15], 1.0, 8, [-8, -7, -1, 1, 2, 3, 7, 7],
+     0.9375),
+    (np.arange(1, 9), [2, 4, 6, 9, 11, 13, 15, 15], 0.46666667, 0, [-1, -2, -3, -4, -5, -6, -7, -8], -1.0),
+    (-np.arange(1, 9), [13, 11, 9, 6, 4, 2, 0, 0], 0.46666667, 15, [-1, -2, -3, -4, -5, -6, -7, -8], 1.0),
+    (np.full(8, 1e-40), [0] * 8, EPS, 0, [0] * 8, EPS),
+    ([1e-3] * 7 + [10], [0] * 7 + [15], 0.66659999, 0, [0] * 7 + [-8], -1.25),
+]
+
+
+@pytest.mark.parametrize("row,qa,sa,za,qs,ss", DEGENERATE)
+def test_degenerate_rows(row, qa, sa, za, qs, ss):
+    w = np.asarray(row, np.float32)[None]
+    c, s, z = O.compress_weight(w, (1,), "int4_asym", 8)
+    assert c.ravel().tolist() == list(qa) and int(z.ravel()[0]) == za
+    assert np.float32(s.ravel()[0]) == np.float32(sa)
+    c, s, _ = O.compress_weight(w, (1,), "int4_sym", 8)
+    assert c.ravel().tolist() == list(qs) and np.float32(s.ravel()[0]) == np.float32(ss)
+
+
+# test_weights_compression.py:700-775 (test_quantization_error_calculation)
+L = np.arange(0, 256, 17, dtype=np.float32)
+TWO = np.vstack((L * 1.2, L * 3.4))
+LA = np.arange(0, 16, dtype=np.float32)
+TWOA = np.vstack((LA * 1.2, LA * 3.4))
+LS = np.arange(-8, 7, dtype=np.float32)
+TWOS = np.vstack((LS * 1.2, LS * 3.4))
+ERR = [
+    (TWO, "int8_asym", -1, 0, 1e-8), (TWOS, "int4_sym", -1, 0, 1e-8), (TWOA, "int4_asym", -1, 0, 1e-8),
+    (np.hstack((TWOS, np.vstack((LS * 5.6, LS * 7.8)))), "int4_sym", 15, 0, 1e-8),
+    (np.hstack((TWOA, np.vstack((LA * 5.6, LA * 7.8)))), "int4_asym", 16, 0, 1e-8),
+    (TWO[:, 1:-1], "int8_asym", -1, 239, 1), (TWO.T, "int8_asym", -1, 46818, 1),
+    (TWOA, "int4_sym", -1, 4.12, 1), (TWOA.T, "int4_sym", -1, 0.63, 1),
+    (TWOA[:, 1:-1], "int4_asym", -1, 1.49, 1), (TWOA.T, "int4_asym", -1, 162, 1),
+]
+
+
+@pytest.mark.parametrize("w,mode,gs,ref,atol", ERR)
+def test_quantization_error_calculation(w, mode, gs, ref, atol):
+    assert np.allclose(O.get_integer_quantization_error(w, 1, mode, gs, "max_mean"), ref, atol=atol)
+
+
+def test_calculate_scale_per_group():
+    # test_weights_compression.py:788-830
+    W = np.array([[-4, -3, -2, -1], [0, 11, 2, 3]])
+    am = np.array([4, 2, 11, 3])
+    cases = [(W, am.reshape(2, 2, 1), 1, 2), (W, np.abs(W).reshape(2, 1, 4), 0, 1),
+             (W.reshape(1, 2, 4, 1), am.reshape(1, 2, 2, 1, 1), 2, 2),
+             (W.reshape(2, 2, 2), np.array([4, 3, 2, 11]).reshape(2, 1, 1, 2), 1, 2),
+             (W.reshape(2, 2, 2), np.array([4, 11, 2, 3]).reshape(1, 1, 2, 2), 0, 2)]
+    for w, ref, axis, gs in cases:
+        r, ax = O.reshape_weight_for_grouped_quantization(w, axis, gs)
+        assert np.allclose(np.max(np.abs(r), axis=ax, keepdims=True), ref)
+    with pytest.raises(O.InvalidGroupSizeError):
+        O.reshape_weight_for_grouped_quantization(W, 1, 3)
+
+
+def test_pack_roundtrip():
+    # tests/torch/function_hook/quantization/test_weights_compression.py:557-572
+    rng = np.random.default_rng(0)
+    u = rng.integers(0, 16, (4, 4)).astype(np.uint8)
+    p = O.pack_uint4(u)
+    assert p.dtype == np.uint8 and p.size * 2 == u.size and p.shape == (8, 1)
+    assert np.array_equal(O.unpack_uint4(p).reshape(u.shape), u)
+    i = rng.integers(-8, 8, (4, 4)).astype(np.int8)
+    assert np.array_equal(O.unpack_int4(O.pack_int4(i)).reshape(i.shape), i)
+    with pytest.raises(TypeError):
+        O.pack_uint4(i)
+
+
+def test_reducer_literals():
+    # tests/common/test_reducers_and_aggregators.py:62, 264-295 (axes None == all axes)
+    x = np.array([[[1, 2, 0], [1, -3, 10]], [[-1, 2, -3], [4, 5, -6]]], np.float32)
+    mean_var = {(0, 1, 2): 16.1666, (0,): 14.25, (0, 1): 15.875}
+    mean_abs_max = {(0, 1, 2): 10.0, (0,): 4.16666, (0, 1): 6.33333}
+    max_var = {(0, 1, 2): 16.1666, (0,): 64.0, (0, 1): 36.1875}
+    for axes, ref in mean_var.items():
+        assert np.isclose(O.mean_variance_reducer(x, axes), ref, atol=1e-4)
+    for axes, ref in mean_abs_max.items():
+        assert np.isclose(O.mean_abs_max_reducer(x, axes), ref, atol=1e-4)
+    for axes, ref in max_var.items():
+        assert np.isclose(O.max_variance_reducer(x, axes), ref, atol=1e-4)
+
+
+def test_hawq_literals():
+    # tests/common/test_reducers_and_aggregators.py:713-726
+    assert np.isclose(O.hawq_aggregate([np.arange(10, dtype=np.float32)]), 57.0)
+    assert np.isclose(O.hawq_aggregate([np.arange(12, dtype=np.float32).reshape(2, 6),
+                                        np.arange(24, dtype=np.float32).reshape(4, 6)]), 181.92361111)
+    assert np.isclose(O.hawq_aggregate([np.arange(8 * i, dtype=np.float32).reshape(1, 8, i) for i in range(1, 5)]),
+                      165.61627, rtol=1e-6)
+
+
+def test_mixed_precision_literals():
+    # tests/cross_fw/test_templates/template_test_weights_compression.py:52-58
+    x = np.array([[[-4, 1, 2], [0, 0, 0], [0, 0, 0]]], np.float32)
+    assert np.isclose(O.max_variance_reducer(x, (1,)), 3.555555, atol=1e-5)
+    assert np.isclose(O.mean_variance_reducer(x, (1,)), 1.555555, atol=1e-5)
+    assert np.isclose(O.mean_abs_max_reducer(x, (1,)), 2.333333, atol=1e-5)
+    assert np.isclose(O.hawq_aggregate([x]), (16 + 1 + 4) * 2 / 9)
+
+
+def test_x86_int32_overflow_rule():
+    v = np.array([2.5e9, -2.5e9, np.nan, 3.7, -3.7, 2147483520.0], np.float32)
+    assert O.x86_cvtt_int32(v).tolist() == [-2 ** 31, -2 ** 31, -2 ** 31, 3, -3, 2147483520]
