@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""
+bench.py -- throughput of the weight-compression lowering hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload llama3-8b-int4sym-g128]
+
+A "step" is one pass of the fused lowering (group min/max -> scale -> round -> nibble pack) over every linear
+weight of a Llama-3-8B-shaped model (7 shapes x 32 layers, bf16, random init, resident in HBM), INT4_SYM
+group_size=128, through the C ABI (nncf_amd_int_quantize_batched).  Metric: GB/s of bf16 weights compressed
+(input bytes / wall time), whole job.  N > 1: one process per GPU (torchrun), every rank compresses its own
+model-sized shard of layers, no data-path collective (weak scaling; --gather adds the RCCL all-gather of the
+compressed payload and reports it separately).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# [out, in] linear shapes per decoder layer: q, k, v, o, gate, up, down
+SHAPES = {
+    "llama3-8b": ([(4096, 4096), (1024, 4096), (1024, 4096), (4096, 4096), (14336, 4096), (14336, 4096),
+                   (4096, 14336)], 32),
+    "llama3-70b": ([(8192, 8192), (1024, 8192), (1024, 8192), (8192, 8192), (28672, 8192), (28672, 8192),
+                    (8192, 28672)], 80),
+    "mixtral-8x7b-experts": ([(14336, 4096), (14336, 4096), (4096, 14336)] * 8, 32),
+    "tiny": ([(512, 1024), (256, 1024), (1024, 512)], 2),
+}
+WORKLOADS = {
+    # name: (geometry, mode, group_size)
+    "llama3-8b-int4sym-g128": ("llama3-8b", "int4_sym", 128),
+    "llama3-8b-int4asym-g128": ("llama3-8b", "int4_asym", 128),
+    "llama3-8b-int8asym": ("llama3-8b", "int8_asym", -1),
+    "llama3-70b-int4sym-g128": ("llama3-70b", "int4_sym", 128),
+    "mixtral-nf4-g32": ("mixtral-8x7b-experts", "nf4", 32),
+    "mixtral-mxfp4-g32": ("mixtral-8x7b-experts", "mxfp4", 32),
+    "tiny-int4sym-g128": ("tiny", "int4_sym", 128),
+}
+
+
+def algorithmic_bytes_per_elem(mode, gs, cols):
+    """bf16 in (2 B) + packed 4-bit (0.5 B) or 8-bit (1 B) out + fp32 scale (+ int32 zp) per group."""
+    g = gs if gs != -1 else cols
+    out = 1.0 if mode.startswith("int8") else 0.5
+    params = 4.0 / g * (2 if mode.endswith("asym") else 1)
+    return 2.0 + out + params
+
+
+class Job:
+    """One rank's resident weights + preallocated outputs + C-ABI descriptor arrays."""
+
+    def __init__(self, geometry, mode, gs, device, layers=None, seed=0):
+        import ctypes
+
+        from nncf_amd import _lib
+
+        self._lib, self._ct = _lib, ctypes
+        shapes, n_layers = SHAPES[geometry]
+        n_layers = layers or n_layers
+        self.mode, self.gs, self.device = mode, gs, device
+        self.is_int = mode.startswith("int")
+        four = not mode.startswith("int8")
+        self.weights, self.outs, self.scales, self.zps = [], [], [], []
+        gen = torch.Generator(device=device)
+        for layer in range(n_layers):
+            gen.manual_seed(seed * 100003 + layer)
+            for (o, i) in shapes:
+                w = (torch.randn(o, i, device=device, generator=gen, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+                g = gs if gs != -1 else i
+                self.weights.append(w)
+                self.outs.append(torch.empty(o * i // 2 if four else o * i, dtype=torch.uint8, device=device))
+                self.scales.append(torch.empty(o * (i // g), dtype=torch.float32, device=device))
+                self.zps.append(torch.empty(o * (i // g), dtype=torch.int32, device=device)
+                                if mode.endswith("asym") else None)
+        n = len(self.weights)
+        self.n = n
+        self.elems = sum(w.numel() for w in self.weights)
+        self.in_bytes = 2 * self.elems
+        self.alg_bytes = sum(w.numel() * algorithmic_bytes_per_elem(mode, gs, w.shape[1]) for w in self.weights)
+        VP = ctypes.c_void_p * n
+        I64 = ctypes.c_int64 * n
+        self.c_w = VP(*[w.data_ptr() for w in self.weights])
+        self.c_rows = I64(*[w.shape[0] for w in self.weights])
+        self.c_cols = I64(*[w.shape[1] for w in self.weights])
+        self.c_out = VP(*[t.data_ptr() for t in self.outs])
+        self.c_scale = VP(*[t.data_ptr() for t in self.scales])
+        self.c_zp = VP(*[t.data_ptr() if t is not None else None for t in self.zps]) if mode.endswith("asym") else None
+        self.stream = torch.cuda.current_stream(device)
+
+    def step(self):
+        L, ct = self._lib.lib(), self._ct
+        s = ct.c_void_p(self.stream.cuda_stream)
+        if self.is_int:
+            four = not self.mode.startswith("int8")
+            st = L.nncf_amd_int_quantize_batched(self.n, self.c_w, self._lib.BF16, self.c_rows, self.c_cols, self.gs,
+                                                 self._lib.MODE_ID[self.mode], None if four else self.c_out,
+                                                 self.c_out if four else None, self.c_scale, self.c_zp, s)
+            self._lib.check(st)
+        else:
+            for i, w in enumerate(self.weights):
+                st = L.nncf_amd_float_quantize(self.c_w[i], self._lib.BF16, w.shape[0], w.shape[1], 1, self.gs,
+                                               self._lib.MODE_ID[self.mode], None, None, None, self.c_out[i],
+                                               self.c_scale[i], None, None, s)
+                self._lib.check(st)
+
+
+def cpu_baseline(geometry, mode, gs, budget_s=12.0):
+    """The reference's torch-CPU op chain (oracle/torch_chain.py, a port) on the host cores, bounded sample."""
+    from oracle.torch_chain import compress_int_torch
+
+    if not mode.startswith("int"):
+        return None
+    shapes, _ = SHAPES[geometry]
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    gen = torch.Generator().manual_seed(0)
+    done_bytes, t_total, used = 0, 0.0, []
+    for (o, i) in shapes:
+        w = (torch.randn(o, i, generator=gen) * 0.02).to(torch.bfloat16)
+        t0 = time.perf_counter()
+        compress_int_torch(w, mode, gs, pack=True)
+        dt = time.perf_counter() - t0
+        t_total += dt
+        done_bytes += 2 * w.numel()
+        used.append(f"{o}x{i}")
+        if t_total > budget_s:
+            break
+    return {"value": round(done_bytes / t_total / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"torch-CPU op chain + pack on {len(used)} tensors of one layer ({', '.join(used)}), bf16, "
+                      f"{mode} g{gs}, {t_total:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="llama3-8b-int4sym-g128", choices=sorted(WORKLOADS))
+    ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug)")
+    ap.add_argument("--gather", action="store_true", help="also time an RCCL all-gather of the compressed payload")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    geometry, mode, gs = WORKLOADS[args.workload]
+    job = Job(geometry, mode, gs, device, layers=args.layers or None, seed=rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-side timing with HIP events on the launch stream (roofline leg)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_steps = max(3, min(args.steps, 10))
+    with torch.cuda.stream(job.stream):
+        ev0.record(job.stream)
+        for _ in range(ev_steps):
+            job.step()
+        ev1.record(job.stream)
+    torch.cuda.synchronize()
+    dev_ms_per_step = ev0.elapsed_time(ev1) / ev_steps
+
+    gather_ms = None
+    if args.gather and dist is not None:
+        payload = torch.cat([t.view(torch.uint8) for t in job.outs] + [t.view(torch.uint8) for t in job.scales])
+        out = torch.empty(world * payload.numel(), dtype=torch.uint8, device=device)
+        barrier()
+        t1 = time.perf_counter()
+        dist.all_gather_into_tensor(out, payload)
+        barrier()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_in_bytes = job.in_bytes * world
+        value = total_in_bytes / (elapsed / args.steps) / 1e9
+        achieved = job.alg_bytes / (dev_ms_per_step * 1e-3) / 1e9
+        kernel = "k_grouped<IntPolicy,bf16,LPG=16,U=4>" if mode.startswith("int4") and gs == 128 else "k_grouped/k_row"
+        res = {
+            "metric": "GB/s bf16 weights compressed (node)",
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{geometry}-shaped linears x{len(job.weights) // len(SHAPES[geometry][0])} layers, "
+                                   f"bf16 random-init, {mode} group_size={gs}, fused quantize+pack, data-free RTN",
+                       "tensors_per_step": job.n, "elements_per_step_per_gpu": job.elems,
+                       "partition": "each rank compresses its own model-sized set of layers; no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": kernel, "launches_per_step": job.n,
+                         "avg_launch_us": round(dev_ms_per_step * 1e3 / job.n, 3),
+                         "algorithmic_bytes_per_launch": round(job.alg_bytes / job.n, 1),
+                         "device_ms_per_step": round(dev_ms_per_step, 4)},
+        }
+        if gather_ms is not None:
+            res["allgather_ms"] = round(gather_ms, 3)
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(geometry, mode, gs)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

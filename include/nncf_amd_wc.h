@@ -1,0 +1,194 @@
+/*
+ * nncf_amd_wc.h -- C ABI of libnncf_amd_wc.so: the MI355X (gfx950) implementation of NNCF's
+ * weight-compression lowering hot path.
+ *
+ * Conventions
+ *  - every pointer argument is a DEVICE pointer unless its name ends in `_host`;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *    stream-ordered and asynchronous; no entry point allocates or synchronizes;
+ *  - the caller owns every buffer; "nullable" outputs are skipped when NULL;
+ *  - return value: NNCF_AMD_OK (0) or a negative nncf_amd_status; nncf_amd_last_error()
+ *    gives a thread-local message for the last failure;
+ *  - a weight is described as a contiguous [outer, r, inner] array that is reduced along `r`
+ *    in groups of `group_size` (group_size == -1 means one group of length r).  This is the
+ *    reference's `reshape_weight_for_grouped_quantization` view
+ *    (src/nncf/quantization/algorithms/weight_compression/weight_lowering.py:57-81);
+ *    torch nn.Linear weights [out, in] reduced along the last axis are (outer=out, r=in, inner=1).
+ *    Per-group parameters (scale, zero point) are laid out [outer, r/group_size, inner], i.e. the
+ *    reference's keepdims shape [outer, r/gs, 1, inner] flattened.
+ *
+ * Reference paths are relative to the nncf 3.2.0 checkout; "WL" abbreviates
+ * src/nncf/quantization/algorithms/weight_compression/weight_lowering.py.
+ */
+#ifndef NNCF_AMD_WC_H
+#define NNCF_AMD_WC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    NNCF_AMD_OK = 0,
+    NNCF_AMD_ERR_BAD_ARG = -1,    /* null/negative/inconsistent argument                       */
+    NNCF_AMD_ERR_GROUP_SIZE = -2, /* r % group_size != 0  (nncf.errors.InvalidGroupSizeError)  */
+    NNCF_AMD_ERR_DTYPE = -3,      /* unsupported dtype enum                                     */
+    NNCF_AMD_ERR_MODE = -4,       /* unsupported mode enum for this entry point                 */
+    NNCF_AMD_ERR_LAUNCH = -5,     /* hipGetLastError() != hipSuccess after a launch             */
+    NNCF_AMD_ERR_WORKSPACE = -6,  /* workspace missing or too small                             */
+    NNCF_AMD_ERR_UNSUPPORTED = -7 /* valid request this build does not implement (caller error) */
+} nncf_amd_status;
+
+typedef enum { NNCF_AMD_F32 = 0, NNCF_AMD_F16 = 1, NNCF_AMD_BF16 = 2 } nncf_amd_dtype;
+
+/* CompressWeightsMode subset on the path (src/nncf/parameters.py:73-120) */
+typedef enum {
+    NNCF_AMD_INT8_ASYM = 0,
+    NNCF_AMD_INT8_SYM = 1,
+    NNCF_AMD_INT4_ASYM = 2,
+    NNCF_AMD_INT4_SYM = 3,
+    NNCF_AMD_NF4 = 4,
+    NNCF_AMD_MXFP4 = 5, /* e2m1 values, E8M0 power-of-two scale */
+    NNCF_AMD_FP4 = 6    /* e2m1 values, fp32 scale              */
+} nncf_amd_mode;
+
+typedef enum { NNCF_AMD_ZP_NONE = 0, NNCF_AMD_ZP_I32 = 1, NNCF_AMD_ZP_F32 = 2 } nncf_amd_zp_dtype;
+typedef enum { NNCF_AMD_ERR_MAX_MEAN = 0, NNCF_AMD_ERR_FROBENIUS = 1 } nncf_amd_error_reduction;
+
+/* Library identity / diagnostics. */
+int nncf_amd_version(void);               /* major*10000 + minor*100 + patch */
+const char* nncf_amd_last_error(void);    /* thread-local, never NULL         */
+const char* nncf_amd_status_string(int status);
+
+/*
+ * Fused integer lowering: group min/max -> scale[, zero point] -> round -> clip [-> nibble pack] [-> dequantize].
+ * Replaces, in one pass over the weight:
+ *   calculate_integer_quantization_params   WL:292-326  (asym: quantization/fake_quantize.py:322-350,
+ *                                                         sym: _calculate_signed_scale WL:629-649)
+ *   _calculate_integer_quantized_weight     WL:652-684
+ *   do_integer_quantization                 WL:451-508
+ *   do_integer_dequantization               WL:428-448   (when dq_out != NULL -> integer_quantize_dequantize_weight WL:511-554)
+ *   pack_int4 / pack_uint4                  src/nncf/torch/quantization/quantize_functions.py:417-461 (when packed_out != NULL)
+ *
+ *   scale_in  nullable: precomputed scale per group; when given no statistics are computed.
+ *   zp_in     nullable: precomputed zero point per group (zp_dtype says int32 or float32, WL:679-680).
+ *             For asymmetric modes scale_in and zp_in must be given together (WL:472-477).
+ *   codes_out nullable: int8 (sym) / uint8 (asym), one code per element, same layout as weight.
+ *   packed_out nullable: 4-bit modes only, inner == 1 only; byte k = (u[2k] & 15) | (u[2k+1] << 4) over the
+ *             flattened codes with u = code + 8 for INT4_SYM; n_elements/2 bytes.
+ *   scale_out nullable: fp32 [n_groups] (written also when scale_in is given: a verbatim copy).
+ *   zp_out    nullable: int32 [n_groups] (asymmetric modes computing their own parameters only).
+ *   dq_out    nullable: fp32 dequantized weight, same layout as weight.
+ */
+int nncf_amd_int_quantize(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
+                          int64_t group_size, int mode, const float* scale_in, const void* zp_in, int zp_dtype,
+                          void* codes_out, uint8_t* packed_out, float* scale_out, int32_t* zp_out, float* dq_out,
+                          void* stream);
+
+/*
+ * Batched form of nncf_amd_int_quantize for data-free compression of many [rows, cols] weights (inner == 1,
+ * no precomputed parameters): one host call, device work queued back-to-back on `stream`.
+ * Replaces the sequential per-weight loop of PTWeightCompressionAlgoBackend.transform_model
+ * (src/nncf/quantization/algorithms/weight_compression/torch_backend.py:442-477) for the lowering part.
+ * All arrays are HOST arrays of length n; pointers inside them are device pointers (entries may be NULL
+ * where the single-tensor call allows NULL).
+ */
+int nncf_amd_int_quantize_batched(int n, const void* const* weights_host, int w_dtype, const int64_t* rows_host,
+                                  const int64_t* cols_host, int64_t group_size, int mode,
+                                  void* const* codes_out_host, uint8_t* const* packed_out_host,
+                                  float* const* scale_out_host, int32_t* const* zp_out_host, void* stream);
+
+/*
+ * Integer dequantization from unpacked codes: (int32(q) - zp) * scale.  WL:428-448.
+ *   codes: int8 (codes_signed != 0) or uint8; zp nullable (zp_dtype as above).
+ */
+int nncf_amd_int_dequantize(const void* codes, int codes_signed, int64_t outer, int64_t r, int64_t inner,
+                            int64_t group_size, const float* scale, const void* zp, int zp_dtype, float* dq_out,
+                            void* stream);
+
+/*
+ * Quantization error of integer Q->DQ:  max over channels of mean((dq-w)^2) or Frobenius norm of (dq-w).
+ * Replaces get_integer_quantization_error WL:329-374 (mean is taken over the whole reduction axis r, the
+ * max over the remaining [outer, inner] channels).  result: one fp32 on the device.
+ * workspace: at least nncf_amd_int_quant_error_workspace(outer, inner) bytes.
+ */
+size_t nncf_amd_int_quant_error_workspace(int64_t outer, int64_t inner);
+int nncf_amd_int_quant_error(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
+                             int64_t group_size, int mode, int reduction, float* result, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/*
+ * Nibble packing, standalone.  src/nncf/torch/quantization/quantize_functions.py:417-473.
+ *   pack_u4: in uint8 [n] (n even) -> out uint8 [n/2];   pack_i4: in int8 (+8 bias first).
+ *   unpack_u4 / unpack_i4: the inverses (out has 2*n_packed entries).
+ */
+int nncf_amd_pack_u4(const uint8_t* in, int64_t n, uint8_t* out, void* stream);
+int nncf_amd_pack_i4(const int8_t* in, int64_t n, uint8_t* out, void* stream);
+int nncf_amd_unpack_u4(const uint8_t* in, int64_t n_packed, uint8_t* out, void* stream);
+int nncf_amd_unpack_i4(const uint8_t* in, int64_t n_packed, int8_t* out, void* stream);
+
+/*
+ * Fused float-codebook lowering (NF4 / MXFP4 / FP4): group abs-max -> scale (E8M0 power of two for MXFP4)
+ * -> normalize -> nearest quantile.  Replaces
+ *   calculate_float_quantization_params   WL:84-128
+ *   _calculate_normalized_weight          WL:613-626
+ *   _calculate_float_quantized_weight     WL:557-586   (NF4: searchsorted on CENTER_OF_NF4_QUANTILES;
+ *                                                       e2m1: nearest with ties to the even quantile index)
+ *   do_float_quantization / do_float_dequantization / float_quantize_dequantize_weight  WL:131-289
+ *   values_out nullable: fp32 quantile VALUES (what the reference's torch/numpy path returns, WL:585-586).
+ *   codes_out  nullable: uint8 one 4-bit code per element.  NF4: index into NF4_QUANTILES;
+ *              e2m1: OCP FP4 bit pattern (sign<<3 | exp<<1 | mantissa), the reference's single zero -> 0b0000.
+ *   packed_out nullable: inner == 1 only; two codes per byte, low nibble = even element.
+ *   scale_out  nullable: fp32 per group.   scale_e8m0_out nullable (MXFP4 only): uint8 log2(scale)+127.
+ *   dq_out     nullable: fp32 value * scale.
+ */
+int nncf_amd_float_quantize(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
+                            int64_t group_size, int mode, const float* scale_in, float* values_out,
+                            uint8_t* codes_out, uint8_t* packed_out, float* scale_out, uint8_t* scale_e8m0_out,
+                            float* dq_out, void* stream);
+
+/*
+ * Activation-statistics reducers over x = [batch, tokens, hidden] (contiguous, dtype x_dtype).
+ * Replace TensorReducerBase._reduce_out_of_place of
+ *   MeanReducer(axes=(0,1))          src/nncf/common/tensor_statistics/collectors.py:512-516
+ *   MeanVarianceReducer(axes=(1,))   :519-524      MaxVarianceReducer(axes=(1,))  :527-532
+ *   MeanAbsMaxReducer(axes=(1,))     :535-540      HAWQAggregator's sum(x*x)      :929-933
+ * mean_out: fp32 [hidden] (mean over batch and tokens; the caller rounds to x's dtype like torch.mean does).
+ * stats_out: fp32 [4] = { mean(var(x,1)), max(var(x,1)), mean(max|x| over axis 1), sum(x*x) }, each
+ *            nullable-by-flag via `want_mean` / `want_stats`.
+ * workspace: nncf_amd_reduce_workspace(batch, tokens, hidden) bytes.
+ */
+size_t nncf_amd_reduce_workspace(int64_t batch, int64_t tokens, int64_t hidden);
+int nncf_amd_reduce_activation_stats(const void* x, int x_dtype, int64_t batch, int64_t tokens, int64_t hidden,
+                                     float* mean_out, float* stats_out, void* workspace, size_t workspace_bytes,
+                                     void* stream);
+
+/*
+ * GPTQ Hessian accumulation  H = beta*H + alpha * X^T X  (fp32, MFMA f32 tiles; full symmetric H is written).
+ * Replaces the loop body of GPTQ._calculate_hessian
+ * (src/nncf/quantization/algorithms/weight_compression/gptq.py:237-240) with beta = n/(n+b), alpha = 2/(n+b).
+ *   x: [tokens, k] row-major (x_dtype), h: [k, k] fp32.
+ */
+int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k, float alpha,
+                                float beta, void* stream);
+
+/*
+ * GPTQ in-block column sweep (gptq.py:298-361, one block of `count` <= 128 columns starting at column i1).
+ * For every row independently: at group starts (re)compute scale[, zp] from `weight` (the not-in-block-updated
+ * tensor, gptq.py:315-333), quantize-dequantize the column, propagate err = (w-q)/Hinv[c,c] to the remaining
+ * columns of the block.  Writes q into quantized[:, i1:i1+count], err into err_block [rows, count],
+ * appends scales/zps at group index (i1+i)/group_size.
+ *   weight, quantized: [rows, k] fp32;  hinv: [k, k] fp32 upper Cholesky factor of H^-1;
+ *   scales: fp32 [rows, k/group_size]; zps: int32 same shape (asymmetric integer modes) or NULL.
+ * The trailing update W[:, i2:] -= Err @ Hinv[i1:i2, i2:] (gptq.py:363) is a plain GEMM left to the caller.
+ */
+int nncf_amd_gptq_block(const float* weight, float* quantized, float* err_block, const float* hinv, int64_t rows,
+                        int64_t k, int64_t i1, int64_t count, int64_t group_size, int mode, float* scales,
+                        int32_t* zps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNCF_AMD_WC_H */

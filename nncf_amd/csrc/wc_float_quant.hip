@@ -1,0 +1,168 @@
+// wc_float_quant.hip -- fused NF4 / MXFP4 / FP4 (e2m1) codebook lowering for gfx950 (policy + C entry point).
+//
+// group abs-max -> scale (/6 for e2m1; E8M0 power of two for MXFP4) -> w/scale -> nearest quantile.
+// The quantile search is a bucket LUT in LDS: floor(n*K) selects a bucket that contains at most one
+// decision boundary (NF4: K=16 over [-1,1]; e2m1: K=2 over [-6.5,6.5]), so
+//     idx = base[bucket] + (n > center[bucket])
+// equals searchsorted(centers, n, side='left') of weight_lowering.py:574 for every float n, and the e2m1
+// tie rule of weight_lowering.py:577-583 is then applied literally on the two neighbouring quantiles.
+#include "wc_e8m0_table.h"
+#include "wc_group_kernels.h"
+
+namespace wc {
+
+// constants.py:17-58, 84-106 (data, bit exact)
+__device__ static const float kNF4Q[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
+                                           -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
+                                           0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f,
+                                           0.33791524171829224f, 0.44070982933044434f, 0.5626170039176941f,
+                                           0.7229568362236023f, 1.0f};
+__device__ static const float kNF4C[15] = {-0.84809643f, -0.6106329f, -0.45999527f, -0.33967942f, -0.2346074f,
+                                           -0.13791174f, -0.045525018f, 0.03979015f, 0.120255254f, 0.20352125f,
+                                           0.29201376f, 0.38931254f, 0.5016634f, 0.6427869f, 0.8614784f};
+__device__ static const float kE2M1Q[15] = {-6.0f, -4.0f, -3.0f, -2.0f, -1.5f, -1.0f, -0.5f, -0.0f,
+                                            0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f};
+// index in kE2M1Q -> OCP e2m1 bit pattern (sign<<3 | exp<<1 | man); the reference's single (negative) zero -> 0b0000
+__device__ static const uint8_t kE2M1Code[15] = {15, 14, 13, 12, 11, 10, 9, 0, 1, 2, 3, 4, 5, 6, 7};
+
+// LDS table layout (floats): [0,40) bucket centers, [40,80) bucket base index (as int bits), [80,96) quantiles,
+// [96,112) codes (as int bits)
+constexpr int kLutCenter = 0, kLutBase = 40, kLutQ = 80, kLutCode = 96;
+
+template <bool NF4>
+struct FloatPolicy {
+    // bucket = clamp(floor(n * K) + OFF, 0, NB-1)
+    static constexpr float K = NF4 ? 16.0f : 2.0f;
+    static constexpr int OFF = NF4 ? 17 : 14;
+    static constexpr int NB = NF4 ? 35 : 29;
+    static constexpr int NQ = NF4 ? 16 : 15;
+    const float* lut;
+    int mode;
+    struct Stat {
+        float amax;
+    };
+    struct Par {
+        float scale;
+    };
+
+    static __device__ __forceinline__ float center(int j) {
+        if constexpr (NF4) return kNF4C[j];
+        return (kE2M1Q[j + 1] + kE2M1Q[j]) / 2;  // constants.py:106
+    }
+    static __device__ __forceinline__ int bucket_of(float n) {
+        int b = __float2int_rd(n * K) + OFF;
+        return b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+    }
+    static __device__ void init_shared(float* lds) {
+        const int t = threadIdx.x;
+        if (t < NB) {
+            // centers falling into bucket t (at most one by construction) and the number of centers below it
+            float c = __builtin_inff();
+            int base = 0;
+            for (int j = 0; j < NQ - 1; ++j) {
+                const int bj = bucket_of(center(j));
+                if (bj < t) ++base;
+                if (bj == t) c = center(j);
+            }
+            lds[kLutCenter + t] = c;
+            lds[kLutBase + t] = __builtin_bit_cast(float, base);
+        }
+        if (t < NQ) {
+            lds[kLutQ + t] = NF4 ? kNF4Q[t] : kE2M1Q[t];
+            lds[kLutCode + t] = __builtin_bit_cast(float, NF4 ? t : (int)kE2M1Code[t]);
+        }
+    }
+    __device__ __forceinline__ FloatPolicy(const GroupArgs& a, const float* lds) : lut(lds), mode(a.mode) {}
+    __device__ __forceinline__ Stat stat_init() const { return {0.0f}; }
+    __device__ __forceinline__ void stat_add(Stat& s, float f) const { s.amax = fmaxf(s.amax, fabsf(f)); }
+    template <int L>
+    __device__ __forceinline__ void stat_lanes(Stat& s) const {
+        s.amax = lanes_allreduce<L>(s.amax, OpMax());
+    }
+    __device__ __forceinline__ void stat_block(Stat& s, float* smem) const {
+        s.amax = block_allreduce<4>(s.amax, OpMax(), smem);
+    }
+    // weight_lowering.py:106-126
+    __device__ __forceinline__ Par compute(const Stat& s) const {
+        float sc = s.amax;
+        if (!NF4) sc = sc / 6.0f;
+        if (fabsf(sc) < kEps) sc = kEps;
+        if (mode == NNCF_AMD_MXFP4) {
+            // 2 ** clip(ceil(log2_f32(sc)), -127, 127): exponent k, bumped unless the correctly rounded
+            // fp32 log2 ties back to k (wc_e8m0_table.h).  sc >= 2^-23 here, so it is a normal number.
+            const uint32_t bits = __builtin_bit_cast(uint32_t, sc);
+            int k = (int)((bits >> 23) & 0xffu) - 127;
+            const uint32_t mant = bits & 0x7fffffu;
+            if (k >= -127 && k <= 127 && mant > kLog2SlackMant[k + 127]) ++k;
+            k = k < -127 ? -127 : (k > 127 ? 127 : k);
+            sc = ldexpf(1.0f, k);
+        }
+        return {sc};
+    }
+    __device__ __forceinline__ Par load(const GroupArgs& a, int64_t g) const { return {a.scale_in[g]}; }
+    __device__ __forceinline__ void store(const GroupArgs& a, int64_t g, const Par& p) const {
+        if (a.scale_out) a.scale_out[g] = p.scale;
+        if (a.e8m0_out) {
+            const uint32_t bits = __builtin_bit_cast(uint32_t, p.scale);
+            int e = (int)((bits >> 23) & 0xffu);  // biased exponent == log2(scale) + 127 for normal powers of two
+            if (e == 0) e = 0;                      // 2^-127 is an fp32 denormal: E8M0 byte 0
+            a.e8m0_out[g] = (uint8_t)e;
+        }
+    }
+    __device__ __forceinline__ void quant(float w, const Par& p, int& code, float& value) const {
+        const float n = w / p.scale;  // weight_lowering.py:626
+        const int b = bucket_of(n);
+        int idx = __builtin_bit_cast(int, lut[kLutBase + b]) + (n > lut[kLutCenter + b] ? 1 : 0);
+        if constexpr (!NF4) {
+            // weight_lowering.py:577-583
+            const int r = idx + 1 > NQ - 1 ? NQ - 1 : idx + 1;
+            const float dl = fabsf(n - lut[kLutQ + idx]);
+            const float dr = fabsf(n - lut[kLutQ + r]);
+            const bool right = (dr < dl) || ((dl == dr) && (((r + 1) & 1) == 0));
+            idx = right ? r : idx;
+        }
+        value = lut[kLutQ + idx];
+        code = __builtin_bit_cast(int, lut[kLutCode + idx]);
+    }
+    __device__ __forceinline__ float dq(int, float value, const Par& p) const { return value * p.scale; }
+    __device__ __forceinline__ int nibble(int code) const { return code; }
+};
+
+}  // namespace wc
+
+extern "C" int nncf_amd_float_quantize(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
+                                       int64_t group_size, int mode, const float* scale_in, float* values_out,
+                                       uint8_t* codes_out, uint8_t* packed_out, float* scale_out,
+                                       uint8_t* scale_e8m0_out, float* dq_out, void* stream) {
+    using namespace wc;
+    if (mode != NNCF_AMD_NF4 && mode != NNCF_AMD_MXFP4 && mode != NNCF_AMD_FP4) {
+        set_error("float_quantize: mode %d is not a float codebook mode", mode);
+        return NNCF_AMD_ERR_MODE;
+    }
+    int64_t gs;
+    int st = check_group_shape("float_quantize", weight, outer, r, inner, group_size, gs);
+    if (st != NNCF_AMD_OK) return st > 0 ? NNCF_AMD_OK : st;
+    if (packed_out && ((outer * r * inner) & 1)) {
+        set_error("float_quantize: packed_out needs an even number of elements");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (scale_e8m0_out && mode != NNCF_AMD_MXFP4) {
+        set_error("float_quantize: scale_e8m0_out is for MXFP4 only");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    GroupArgs a = {};
+    a.w = weight;
+    a.scale_in = scale_in;
+    a.codes = codes_out;
+    a.packed = packed_out;
+    a.values = values_out;
+    a.scale_out = scale_out;
+    a.e8m0_out = scale_e8m0_out;
+    a.dq = dq_out;
+    a.gs = gs;
+    a.inner = inner;
+    a.n_groups = outer * (r / gs) * inner;
+    a.mode = mode;
+    if (mode == NNCF_AMD_NF4) return run_group_op_dtype<FloatPolicy<true>>(w_dtype, a, 0, "float_quantize", (hipStream_t)stream);
+    return run_group_op_dtype<FloatPolicy<false>>(w_dtype, a, 0, "float_quantize", (hipStream_t)stream);
+}

@@ -1,0 +1,352 @@
+// wc_group_kernels.h -- the three group-wise lowering kernel skeletons, shared by the integer
+// (wc_int_quant.hip) and float-codebook (wc_float_quant.hip) policies.
+//
+//   grouped : group = LPG consecutive lanes of one wave (LPG = group bytes / 16, power of two <= 64);
+//             16-byte coalesced loads, UNROLL KiB in flight per wave, DPP reductions, no LDS traffic.
+//   row     : group = one wave or one 256-thread block (long rows: per-channel INT8, fp32 g >= 512 ...);
+//             up to KEEP vectors per thread stay in registers between the statistics and quantize passes.
+//   generic : one thread per group, any group size / inner stride / alignment (small or odd shapes).
+//
+// A Policy supplies the arithmetic:
+//   Policy(const GroupArgs&, float* lds)        per-thread constructor (lds: kPolicyLds floats, block shared)
+//   static void init_shared(float* lds)          fills block-shared tables (followed by __syncthreads())
+//   Stat stat_init(); void stat_add(Stat&, float); template<int L> void stat_lanes(Stat&);
+//   void stat_block(Stat&, float* smem16)        block (4 waves) all-reduce
+//   Par compute(const Stat&); Par load(const GroupArgs&, int64 g); void store(const GroupArgs&, int64 g, const Par&)
+//   void quant(float w, const Par&, int& code, float& value)
+//   float dq(int code, float value, const Par&);  int nibble(int code)
+#pragma once
+#include "wc_common.h"
+
+namespace wc {
+
+struct GroupArgs {
+    const void* w;
+    const float* scale_in;
+    const void* zp_in;
+    int zp_dtype;
+    void* codes;        // 1 byte per element
+    uint8_t* packed;    // 2 elements per byte
+    float* values;      // float policies: fp32 quantile values
+    float* scale_out;
+    int32_t* zp_out;
+    uint8_t* e8m0_out;
+    float* dq;
+    int64_t n_groups;
+    int64_t gs;
+    int64_t inner;
+    int mode;
+};
+
+constexpr int kPolicyLds = 128;  // floats of block-shared table space handed to a policy
+
+template <int E, typename Policy, typename Par>
+__device__ __forceinline__ void emit_vec(const GroupArgs& a, const Policy& pol, const Par& par, const float* f,
+                                         int64_t v) {
+    int code[E];
+    float val[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) pol.quant(f[i], par, code[i], val[i]);
+    if (a.codes) {
+        uint32_t pk[E / 4];
+#pragma unroll
+        for (int i = 0; i < E / 4; ++i) {
+            pk[i] = ((uint32_t)code[4 * i] & 0xffu) | (((uint32_t)code[4 * i + 1] & 0xffu) << 8) |
+                    (((uint32_t)code[4 * i + 2] & 0xffu) << 16) | (((uint32_t)code[4 * i + 3] & 0xffu) << 24);
+        }
+        if constexpr (E == 8) {
+            ((uint2*)a.codes)[v] = make_uint2(pk[0], pk[1]);
+        } else {
+            ((uint32_t*)a.codes)[v] = pk[0];
+        }
+    }
+    if (a.packed) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) pk |= ((uint32_t)pol.nibble(code[i]) & 0xfu) << (4 * i);
+        if constexpr (E == 8) {
+            ((uint32_t*)a.packed)[v] = pk;
+        } else {
+            ((uint16_t*)a.packed)[v] = (uint16_t)pk;
+        }
+    }
+    if (a.values) {
+        float4* o = (float4*)a.values;
+#pragma unroll
+        for (int i = 0; i < E / 4; ++i)
+            o[v * (E / 4) + i] = make_float4(val[4 * i], val[4 * i + 1], val[4 * i + 2], val[4 * i + 3]);
+    }
+    if (a.dq) {
+        float4* o = (float4*)a.dq;
+#pragma unroll
+        for (int i = 0; i < E / 4; ++i)
+            o[v * (E / 4) + i] =
+                make_float4(pol.dq(code[4 * i], val[4 * i], par), pol.dq(code[4 * i + 1], val[4 * i + 1], par),
+                            pol.dq(code[4 * i + 2], val[4 * i + 2], par), pol.dq(code[4 * i + 3], val[4 * i + 3], par));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ grouped
+template <typename Policy, int DT, int LPG, int UNROLL>
+__global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
+    constexpr int E = Elem<DT>::kPerVec;
+    __shared__ float lds[kPolicyLds];
+    Policy::init_shared(lds);
+    __syncthreads();
+    const Policy pol(a, lds);
+    const int64_t nvec = a.n_groups * LPG;
+    const Vec16* __restrict__ wv = (const Vec16*)a.w;
+    const int64_t step = (int64_t)gridDim.x * 256 * UNROLL;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    // a wave covers UNROLL consecutive KiB per iteration; `base` is wave-uniform
+    for (int64_t base = wave_global * 64 * UNROLL; base < nvec; base += step) {
+        Vec16 raw[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t v = base + u * 64 + lane;
+            if (v < nvec) {
+                raw[u] = wv[v];
+            } else {
+                raw[u].w[0] = raw[u].w[1] = raw[u].w[2] = raw[u].w[3] = 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t v = base + u * 64 + lane;
+            const bool live = v < nvec;
+            const int64_t g = v / LPG;
+            float f[E];
+            unpack<DT>(raw[u], f);
+            typename Policy::Par par;
+            if (a.scale_in == nullptr) {
+                typename Policy::Stat st = pol.stat_init();
+#pragma unroll
+                for (int i = 0; i < E; ++i) pol.stat_add(st, f[i]);
+                pol.template stat_lanes<LPG>(st);  // all 64 lanes take part (dead lanes carry zeros)
+                par = pol.compute(st);
+            } else {
+                par = pol.load(a, live ? g : 0);
+            }
+            if (live) {
+                if ((lane & (LPG - 1)) == 0) pol.store(a, g, par);
+                emit_vec<E>(a, pol, par, f, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ row
+template <typename Policy, int DT, int TEAM, int KEEP>
+__global__ __launch_bounds__(256) void k_row(GroupArgs a, int64_t vpg) {
+    constexpr int E = Elem<DT>::kPerVec;
+    constexpr int TEAMS_PER_BLOCK = 256 / TEAM;
+    __shared__ float lds[kPolicyLds];
+    __shared__ float smem[16];
+    Policy::init_shared(lds);
+    __syncthreads();
+    const Policy pol(a, lds);
+    const Vec16* __restrict__ wv = (const Vec16*)a.w;
+    const int t = threadIdx.x % TEAM;
+    const int team = threadIdx.x / TEAM;
+    for (int64_t g0 = (int64_t)blockIdx.x * TEAMS_PER_BLOCK; g0 < a.n_groups;
+         g0 += (int64_t)gridDim.x * TEAMS_PER_BLOCK) {
+        const int64_t g = g0 + team;
+        const bool live_g = g < a.n_groups;  // uniform per team (a team is one or more whole waves)
+        const int64_t vbase = g * vpg;
+        Vec16 keep[KEEP];
+        if (live_g) {
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const int64_t j = t + (int64_t)k * TEAM;
+                if (j < vpg) keep[k] = wv[vbase + j];
+            }
+        }
+        typename Policy::Par par;
+        if (a.scale_in == nullptr) {
+            typename Policy::Stat st = pol.stat_init();
+            if (live_g) {
+#pragma unroll
+                for (int k = 0; k < KEEP; ++k) {
+                    const int64_t j = t + (int64_t)k * TEAM;
+                    if (j < vpg) {
+                        float f[E];
+                        unpack<DT>(keep[k], f);
+#pragma unroll
+                        for (int i = 0; i < E; ++i) pol.stat_add(st, f[i]);
+                    }
+                }
+                for (int64_t j = t + (int64_t)KEEP * TEAM; j < vpg; j += TEAM) {
+                    float f[E];
+                    unpack<DT>(wv[vbase + j], f);
+#pragma unroll
+                    for (int i = 0; i < E; ++i) pol.stat_add(st, f[i]);
+                }
+            }
+            if constexpr (TEAM == 64) {
+                pol.template stat_lanes<64>(st);
+            } else {
+                pol.stat_block(st, smem);  // contains __syncthreads(): live_g is block-uniform for TEAM == 256
+            }
+            par = pol.compute(st);
+        } else {
+            par = pol.load(a, live_g ? g : 0);
+        }
+        if (!live_g) continue;
+        if (t == 0) pol.store(a, g, par);
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int64_t j = t + (int64_t)k * TEAM;
+            if (j < vpg) {
+                float f[E];
+                unpack<DT>(keep[k], f);
+                emit_vec<E>(a, pol, par, f, vbase + j);
+            }
+        }
+        for (int64_t j = t + (int64_t)KEEP * TEAM; j < vpg; j += TEAM) {
+            float f[E];
+            unpack<DT>(wv[vbase + j], f);
+            emit_vec<E>(a, pol, par, f, vbase + j);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ generic
+// element k of group (o, rg, i) lives at ((o*R + rg*gs + k)*inner + i); consecutive threads take consecutive
+// `inner` positions, so inner > 1 layouts (reduction along a non-last axis) stay coalesced.
+template <typename Policy, int DT>
+__global__ __launch_bounds__(256) void k_generic(GroupArgs a) {
+    __shared__ float lds[kPolicyLds];
+    Policy::init_shared(lds);
+    __syncthreads();
+    const Policy pol(a, lds);
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.n_groups) return;
+    const int64_t i = g % a.inner;
+    const int64_t org = g / a.inner;
+    const int64_t first = org * a.gs * a.inner + i;
+    typename Policy::Par par;
+    if (a.scale_in == nullptr) {
+        typename Policy::Stat st = pol.stat_init();
+        for (int64_t k = 0; k < a.gs; ++k) pol.stat_add(st, Elem<DT>::load(a.w, first + k * a.inner));
+        par = pol.compute(st);
+    } else {
+        par = pol.load(a, g);
+    }
+    pol.store(a, g, par);
+    for (int64_t k = 0; k < a.gs; ++k) {
+        const int64_t idx = first + k * a.inner;
+        int code;
+        float val;
+        pol.quant(Elem<DT>::load(a.w, idx), par, code, val);
+        if (a.codes) ((uint8_t*)a.codes)[idx] = (uint8_t)code;
+        if (a.values) a.values[idx] = val;
+        if (a.dq) a.dq[idx] = pol.dq(code, val, par);
+    }
+}
+
+// nibble-packs byte codes (used after the generic kernel): out[k] = ((c[2k]+bias)&15) | ((c[2k+1]+bias)&15) << 4
+__global__ __launch_bounds__(256) static void k_pack_from_codes(const uint8_t* codes, uint8_t* packed, int64_t n_pairs,
+                                                                int bias) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_pairs) return;
+    const uint32_t lo = (uint32_t)(codes[2 * k] + bias) & 15u, hi = (uint32_t)(codes[2 * k + 1] + bias) & 15u;
+    packed[k] = (uint8_t)(lo | (hi << 4));
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static inline int clamp_grid(int64_t blocks) {
+    const int64_t cap = 256 * 16;  // 256 CUs x 16 blocks: enough to fill the chip, rest is grid-strided
+    return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+template <typename Policy, int DT, int LPG>
+static void launch_grouped(const GroupArgs& a, hipStream_t s) {
+    constexpr int U = 4;
+    const int64_t nvec = a.n_groups * LPG;
+    const int64_t blocks = (nvec + 256 * U - 1) / (256 * U);
+    hipLaunchKernelGGL((k_grouped<Policy, DT, LPG, U>), dim3(clamp_grid(blocks)), dim3(256), 0, s, a);
+}
+
+static inline bool is16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// pack_bias: added to byte codes before nibble packing on the generic path (8 for INT4_SYM)
+template <typename Policy, int DT>
+static int run_group_op(GroupArgs a, int pack_bias, const char* what, hipStream_t s) {
+    constexpr int EB = Elem<DT>::kBytes;
+    const bool aligned = is16(a.w) && (!a.codes || is16(a.codes)) && (!a.packed || is16(a.packed)) &&
+                         (!a.dq || is16(a.dq)) && (!a.values || is16(a.values));
+    const int64_t group_bytes = a.gs * EB;
+    if (a.inner == 1 && aligned && group_bytes % 16 == 0) {
+        const int64_t vpg = group_bytes / 16;
+        if (vpg <= 64 && (vpg & (vpg - 1)) == 0) {
+            switch ((int)vpg) {
+                case 1: launch_grouped<Policy, DT, 1>(a, s); break;
+                case 2: launch_grouped<Policy, DT, 2>(a, s); break;
+                case 4: launch_grouped<Policy, DT, 4>(a, s); break;
+                case 8: launch_grouped<Policy, DT, 8>(a, s); break;
+                case 16: launch_grouped<Policy, DT, 16>(a, s); break;
+                case 32: launch_grouped<Policy, DT, 32>(a, s); break;
+                default: launch_grouped<Policy, DT, 64>(a, s); break;
+            }
+            return launch_status(what);
+        }
+        if (vpg <= 512) {
+            hipLaunchKernelGGL((k_row<Policy, DT, 64, 8>), dim3(clamp_grid((a.n_groups + 3) / 4)), dim3(256), 0, s, a, vpg);
+        } else {
+            hipLaunchKernelGGL((k_row<Policy, DT, 256, 8>), dim3(clamp_grid(a.n_groups)), dim3(256), 0, s, a, vpg);
+        }
+        return launch_status(what);
+    }
+    uint8_t* packed = a.packed;
+    a.packed = nullptr;
+    if (packed && !a.codes) {
+        set_error("%s: packed output for this layout (unaligned, odd group size or inner>1) needs codes_out too", what);
+        return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((k_generic<Policy, DT>), dim3((unsigned)((a.n_groups + 255) / 256)), dim3(256), 0, s, a);
+    int st = launch_status(what);
+    if (st != NNCF_AMD_OK) return st;
+    if (packed) {
+        const int64_t n_pairs = a.n_groups * a.gs / 2;
+        hipLaunchKernelGGL(k_pack_from_codes, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s,
+                           (const uint8_t*)a.codes, packed, n_pairs, pack_bias);
+        st = launch_status("pack_from_codes");
+    }
+    return st;
+}
+
+template <typename Policy>
+static int run_group_op_dtype(int w_dtype, const GroupArgs& a, int pack_bias, const char* what, hipStream_t s) {
+    switch (w_dtype) {
+        case NNCF_AMD_F32: return run_group_op<Policy, NNCF_AMD_F32>(a, pack_bias, what, s);
+        case NNCF_AMD_F16: return run_group_op<Policy, NNCF_AMD_F16>(a, pack_bias, what, s);
+        case NNCF_AMD_BF16: return run_group_op<Policy, NNCF_AMD_BF16>(a, pack_bias, what, s);
+        default:
+            set_error("%s: unsupported weight dtype %d", what, w_dtype);
+            return NNCF_AMD_ERR_DTYPE;
+    }
+}
+
+// shared argument validation; returns NNCF_AMD_OK, an error, or +1 for "empty tensor, nothing to do"
+static inline int check_group_shape(const char* what, const void* weight, int64_t outer, int64_t r, int64_t inner,
+                                    int64_t group_size, int64_t& gs) {
+    if (outer < 0 || r < 0 || inner < 0 || (group_size < 1 && group_size != -1)) {
+        set_error("%s: bad shape outer=%lld r=%lld inner=%lld group_size=%lld", what, (long long)outer, (long long)r,
+                  (long long)inner, (long long)group_size);
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    gs = group_size == -1 ? r : group_size;
+    if (outer * r * inner == 0) return 1;
+    if (r % gs != 0) {
+        set_error("Channel size %lld should be divisible by size of group %lld.", (long long)r, (long long)gs);
+        return NNCF_AMD_ERR_GROUP_SIZE;
+    }
+    if (!weight) {
+        set_error("%s: weight is NULL", what);
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    return NNCF_AMD_OK;
+}
+
+}  // namespace wc

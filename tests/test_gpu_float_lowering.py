@@ -1,0 +1,120 @@
+"""GPU parity: HIP NF4 / MXFP4 lowering vs the oracle and the golden fixtures (values bit exact, scales bit exact)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wc_oracle as O
+from tests.gpu_utils import host, representable, to_dev
+from tests.helpers import assert_equal_nan, golden_weight
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(mode, gs):
+    from nncf_amd.parameters import WeightCompressionConfig
+    return WeightCompressionConfig(mode=mode, group_size=gs)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("gs", [-1, 32, 64])
+@pytest.mark.parametrize("mode", ["nf4", "mxfp4"])
+def test_golden_float_lowering(golden, mode, gs, dtype):
+    from nncf_amd import weight_lowering as wl
+    g = golden("float_lowering")
+    w = to_dev(golden_weight(g, dtype), dtype)
+    key = f"{mode}_g{gs}_{dtype}"
+    cw = wl.compress_weight(w, (1,), _cfg(mode, gs))
+    assert_equal_nan(host(cw.scale), g[key + "_scale"], key + " scale")
+    assert_equal_nan(host(cw.tensor), g[key + "_values"], key + " values")
+    if dtype == "f32":
+        assert_equal_nan(host(wl.do_float_dequantization(cw)), g[key + "_dq"], key + " dq")
+        assert_equal_nan(host(wl.float_quantize_dequantize_weight(w, _cfg(mode, gs), (1,))), g[key + "_dq"])
+
+
+@pytest.mark.parametrize("mode", ["nf4", "mxfp4"])
+def test_golden_boundaries(golden, mode):
+    from nncf_amd import weight_lowering as wl
+    g = golden("float_lowering")
+    cw = wl.compress_weight(to_dev(g["w_boundary"], "f32"), (1,), _cfg(mode, 32))
+    assert_equal_nan(host(cw.scale), g[f"boundary_{mode}_scale"], "boundary scale")
+    assert_equal_nan(host(cw.tensor), g[f"boundary_{mode}_values"], "boundary values")
+    mid = "e2m1" if mode == "mxfp4" else "nf4"
+    cw = wl.compress_weight(to_dev(g[f"w_mid_{mid}"], "f32"), (1,), _cfg(mode, -1))
+    assert_equal_nan(host(cw.scale), g[f"mid_{mid}_scale"])
+    assert_equal_nan(host(cw.tensor), g[f"mid_{mid}_values"])
+    sc = torch.from_numpy(g["pre_scale"]).cuda()
+    dq, cw = wl.float_quantize_dequantize_weight(to_dev(g["pre_w"], "f32"), _cfg(mode, 32), None, sc, True)
+    assert_equal_nan(host(cw.tensor), g[f"pre_{mode}_values"])
+    assert_equal_nan(host(dq), g[f"pre_{mode}_dq"])
+    assert cw.scale is sc
+
+
+SHAPES = [((64, 512), 1, 32), ((64, 512), 1, 64), ((9, 512), 1, 128), ((5, 768), 1, -1), ((3, 4096), 1, -1),
+          ((2, 40000), 1, -1), ((10, 30), 1, 15), ((48, 20), 0, 16), ((4, 32, 6), 1, 8), ((17, 64), 1, 8)]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape,axis,gs", SHAPES)
+@pytest.mark.parametrize("mode", ["nf4", "mxfp4", "fp4"])
+def test_oracle_float_shapes(mode, shape, axis, gs, dtype):
+    from nncf_amd import weight_lowering as wl
+    from nncf_amd.weight_lowering import _float_quantize
+    rng = np.random.default_rng(hash((shape, axis, gs)) % 2**31)
+    w32 = representable((rng.standard_normal(shape) * 0.03).astype(np.float32), dtype)
+    w = to_dev(w32, dtype)
+    dq, cw = wl.float_quantize_dequantize_weight(w, _cfg(mode, gs), (axis,), return_compressed_weight=True)
+    rdq, (rv, rs) = O.float_quantize_dequantize_weight(w32, mode, gs, (axis,), return_compressed_weight=True)
+    assert_equal_nan(host(cw.scale), rs, "scale")
+    assert_equal_nan(host(cw.tensor), rv, "values")
+    assert_equal_nan(host(dq), rdq, "dq")
+    # the build's 4-bit codes: LUT[code] == reference value
+    _, codes, _, _, _, e8 = _float_quantize(w, _cfg(mode, gs), (axis,), None, want_values=False, want_codes=True,
+                                            want_e8m0=(mode == "mxfp4"))
+    lut = O.NF4_QUANTILES if mode == "nf4" else O.E2M1_VALUE_OF_CODE
+    assert np.array_equal(lut[host(codes)], rv)
+    if mode == "mxfp4":
+        assert np.array_equal(np.ldexp(np.float32(1), host(e8).astype(np.int32) - 127), rs)
+    if w32.size % 2 == 0 and axis == w32.ndim - 1:
+        fused = wl.compress_weight_packed(w, (axis,), _cfg(mode, gs))
+        c = host(codes).reshape(-1, 2)
+        assert np.array_equal(host(fused.tensor).ravel(), (c[:, 0] | (c[:, 1] << 4)).astype(np.uint8))
+
+
+def test_dense_normalized_grid():
+    """every decision boundary +-2 ulp, saturation, zeros: unit scale via precomputed scale."""
+    from nncf_amd import weight_lowering as wl
+    for mode, centers, hi in (("nf4", O.CENTER_OF_NF4_QUANTILES, 1.5), ("mxfp4", O.CENTER_OF_F4E2M1_QUANTILES, 8.0)):
+        pts = [np.linspace(-hi, hi, 20001).astype(np.float32)]
+        for c in np.concatenate([centers, O.NF4_QUANTILES if mode == "nf4" else O.F4E2M1_QUANTILES]):
+            x = np.float32(c)
+            lo = x
+            up = x
+            for _ in range(3):
+                lo = np.nextafter(lo, np.float32(-np.inf))
+                up = np.nextafter(up, np.float32(np.inf))
+                pts.append(np.array([lo, up], np.float32))
+            pts.append(np.array([x], np.float32))
+        n = np.concatenate(pts + [np.array([0.0, -0.0, 1e-30, -1e-30, 100.0, -100.0], np.float32)])
+        n = n[: n.size // 8 * 8].reshape(-1, 8)
+        sc = np.ones((n.shape[0], 1), np.float32)
+        cw = wl.do_float_quantization(to_dev(n, "f32"), _cfg(mode, 8), None, torch.from_numpy(sc).cuda())
+        rv, _ = O.do_float_quantization(n, mode, 8, None, sc)
+        assert_equal_nan(host(cw.tensor), rv, mode)
+
+
+def test_mx_scale_boundaries_dense():
+    """group maxima 6*2^k*(1+m*2^-23) for every k in [-24, 100], m in [0, 24]: E8M0 exponent parity."""
+    from nncf_amd import weight_lowering as wl
+    rows = []
+    for k in range(-24, 101):
+        for m in range(0, 25):
+            s = np.float32(2.0 ** k) * (np.float32(1) + np.float32(m) * np.float32(2.0 ** -23))
+            r = np.zeros(32, np.float32)
+            r[3] = -s * np.float32(6.0)
+            r[4] = s
+            rows.append(r)
+    w32 = np.stack(rows)
+    cw = wl.compress_weight(to_dev(w32, "f32"), (1,), _cfg("mxfp4", 32))
+    rv, rs, _ = O.compress_weight(w32, (1,), "mxfp4", 32)
+    assert_equal_nan(host(cw.scale), rs, "mx scale")
+    assert_equal_nan(host(cw.tensor), rv, "mx values")

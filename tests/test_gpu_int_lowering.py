@@ -1,0 +1,192 @@
+"""GPU parity: HIP integer lowering (through the C ABI) vs the oracle and the golden fixtures.
+Codes, zero points and packed bytes must be bit exact; scales are compared bit exact as well (the
+arithmetic is IEEE fp32 with the same operation order; north_star allows <=1e-5 relative)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wc_oracle as O
+from tests.gpu_utils import host, representable, to_dev
+from tests.helpers import assert_equal_nan, golden_weight
+
+pytestmark = pytest.mark.gpu
+
+INT_MODES = ("int8_asym", "int8_sym", "int4_asym", "int4_sym")
+
+
+def _cfg(mode, gs):
+    from nncf_amd.parameters import WeightCompressionConfig
+    return WeightCompressionConfig(mode=mode, group_size=gs)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("gs", [-1, 32, 64, 128])
+@pytest.mark.parametrize("mode", INT_MODES)
+def test_golden_int_lowering(golden, mode, gs, dtype):
+    from nncf_amd import weight_lowering as wl
+    g = golden("int_lowering")
+    w = to_dev(golden_weight(g, dtype), dtype)
+    cw = wl.compress_weight(w, (1,), _cfg(mode, gs))
+    key = f"{mode}_g{gs}_{dtype}"
+    assert tuple(cw.tensor.shape) == g[key + "_codes"].shape
+    assert_equal_nan(host(cw.tensor), g[key + "_codes"], key + " codes")
+    assert_equal_nan(host(cw.scale), g[key + "_scale"], key + " scale")
+    if mode.endswith("asym"):
+        assert cw.zero_point.dtype == torch.int32
+        assert_equal_nan(host(cw.zero_point), g[key + "_zp"], key + " zp")
+    else:
+        assert cw.zero_point is None
+    if dtype == "f32":
+        assert_equal_nan(host(wl.do_integer_dequantization(cw)), g[key + "_dq"], key + " dq")
+        dq, cw2 = wl.integer_quantize_dequantize_weight(w, _cfg(mode, gs), (1,), return_compressed_weight=True)
+        assert_equal_nan(host(dq), g[key + "_dq"], key + " fused dq")
+        assert_equal_nan(host(cw2.tensor), g[key + "_codes"], key + " fused codes")
+        if mode.startswith("int4"):
+            packed = wl.pack_uint4(cw.tensor) if mode == "int4_asym" else wl.pack_int4(cw.tensor)
+            assert_equal_nan(host(packed), g[key + "_packed"], key + " packed")
+            fused = wl.compress_weight_packed(w, (1,), _cfg(mode, gs))
+            assert_equal_nan(host(fused.tensor), g[key + "_packed"], key + " fused packed")
+            assert_equal_nan(host(fused.scale), g[key + "_scale"], key + " fused scale")
+            un = wl.unpack_uint4(packed) if mode == "int4_asym" else wl.unpack_int4(packed)
+            assert_equal_nan(host(un).reshape(g[key + "_codes"].shape), g[key + "_codes"], key + " unpack")
+
+
+@pytest.mark.parametrize("mode", INT_MODES)
+def test_golden_precomputed(golden, mode):
+    from nncf_amd import weight_lowering as wl
+    g = golden("int_lowering")
+    w = to_dev(g["pre_w"], "f32")
+    sc = torch.from_numpy(g["pre_scale"]).cuda()
+    zi = torch.from_numpy(g["pre_zp_i32"]).cuda()
+    if mode.endswith("asym"):
+        for zname, z in (("i32", zi), ("f32", zi.float())):
+            dq, cw = wl.integer_quantize_dequantize_weight(w, _cfg(mode, 64), None, sc, z, True)
+            assert_equal_nan(host(cw.tensor), g[f"pre_{mode}_{zname}_codes"])
+            assert_equal_nan(host(dq), g[f"pre_{mode}_{zname}_dq"])
+            assert cw.scale is sc and cw.zero_point is z  # returned verbatim
+        with pytest.raises(ValueError):
+            wl.do_integer_quantization(w, _cfg(mode, 64), None, sc, None)
+    else:
+        dq, cw = wl.integer_quantize_dequantize_weight(w, _cfg(mode, 64), None, sc, None, True)
+        assert_equal_nan(host(cw.tensor), g[f"pre_{mode}_codes"])
+        assert_equal_nan(host(dq), g[f"pre_{mode}_dq"])
+
+
+@pytest.mark.parametrize("red", ["max_mean", "frobenius"])
+@pytest.mark.parametrize("gs", [-1, 64])
+@pytest.mark.parametrize("mode", INT_MODES)
+def test_golden_error_metric(golden, mode, gs, red):
+    # tolerance of the reference's own alignment test (test_compression_functions.py:284-324): reductions reorder
+    from nncf_amd import weight_lowering as wl
+    g = golden("int_lowering")
+    got = wl.get_integer_quantization_error(to_dev(g["err_w"], "f32"), (1,), _cfg(mode, gs), red)
+    np.testing.assert_allclose(got, float(g[f"err_{mode}_g{gs}_{red}"]), rtol=1e-4, atol=1e-6)
+
+
+SHAPES = [
+    # (shape, reduction axis, group size): every kernel path -- grouped (LPG 1..64), row (wave / block teams),
+    # generic (odd sizes, inner > 1)
+    ((64, 512), 1, 128), ((64, 512), 1, 64), ((64, 512), 1, 32), ((33, 512), 1, 16), ((17, 64), 1, 8),
+    ((7, 1024), 1, 512), ((5, 768), 1, -1), ((3, 4096), 1, -1), ((2, 14336), 1, -1), ((2, 40000), 1, -1),
+    ((10, 30), 1, 15), ((10, 30), 1, -1), ((6, 7), 1, -1), ((48, 20), 0, 16), ((48, 20), 0, -1),
+    ((4, 32, 6), 1, 8), ((2, 3, 64), 2, 32), ((1, 128), 1, 128), ((1, 8), 1, 4), ((513, 256), 1, 128),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape,axis,gs", SHAPES)
+@pytest.mark.parametrize("mode", INT_MODES)
+def test_oracle_int_shapes(mode, shape, axis, gs, dtype):
+    from nncf_amd import weight_lowering as wl
+    rng = np.random.default_rng(hash((shape, axis, gs)) % 2**31)
+    w32 = representable((rng.standard_normal(shape) * 0.03).astype(np.float32), dtype)
+    w = to_dev(w32, dtype)
+    dq, cw = wl.integer_quantize_dequantize_weight(w, _cfg(mode, gs), (axis,), return_compressed_weight=True)
+    rdq, (rc, rs, rz) = O.integer_quantize_dequantize_weight(w32, mode, gs, (axis,), return_compressed_weight=True)
+    assert_equal_nan(host(cw.tensor), rc, "codes")
+    assert_equal_nan(host(cw.scale), rs, "scale")
+    if rz is not None:
+        assert_equal_nan(host(cw.zero_point), rz, "zp")
+    assert_equal_nan(host(dq), rdq, "dq")
+    s2, z2 = wl.calculate_integer_quantization_params(w, (axis,), _cfg(mode, -1))
+    rs2, rz2 = O.calculate_integer_quantization_params(w32, (axis,), mode)
+    assert_equal_nan(host(s2), rs2, "params scale")
+    if rz2 is not None:
+        assert_equal_nan(host(z2), rz2, "params zp")
+    if mode.startswith("int4") and w32.size % 2 == 0 and axis == w32.ndim - 1:
+        fused = wl.compress_weight_packed(w, (axis,), _cfg(mode, gs))
+        ref = O.pack_uint4(rc) if mode == "int4_asym" else O.pack_int4(rc)
+        assert_equal_nan(host(fused.tensor), ref, "fused packed")
+
+
+def test_adversarial_values_match_oracle():
+    """rows built to hit ties (x.5), near-ties, saturation, denormals, huge values, constant groups."""
+    from nncf_amd import weight_lowering as wl
+    rng = np.random.default_rng(11)
+    rows = []
+    for _ in range(64):
+        s = np.float32(rng.uniform(0.001, 3.0))
+        k = rng.integers(-8, 8, 128).astype(np.float32) + 0.5
+        r = k * s
+        r[0], r[1] = -8 * s, 7 * s  # pin min/max so that the scale is s (sym) or near it
+        r[2::7] = np.nextafter(r[2::7], np.float32(np.inf))
+        r[3::7] = np.nextafter(r[3::7], np.float32(-np.inf))
+        rows.append(r.astype(np.float32))
+    rows.append(np.full(128, 1e-40, np.float32))
+    rows.append(np.full(128, -300.0, np.float32))
+    rows.append(np.concatenate([np.full(64, 3e38, np.float32), np.full(64, -3e38, np.float32)]))
+    rows.append(np.concatenate([np.zeros(127, np.float32), np.float32([1e-30])]))
+    w32 = np.stack(rows)
+    w = to_dev(w32, "f32")
+    for mode in INT_MODES:
+        for gs in (128, 32, -1):
+            cw = wl.compress_weight(w, (1,), _cfg(mode, gs))
+            rc, rs, rz = O.compress_weight(w32, (1,), mode, gs)
+            assert_equal_nan(host(cw.tensor), rc, f"{mode} g{gs} codes")
+            assert_equal_nan(host(cw.scale), rs, f"{mode} g{gs} scale")
+            if rz is not None:
+                assert_equal_nan(host(cw.zero_point), rz, f"{mode} g{gs} zp")
+
+
+def test_error_behaviour():
+    from nncf_amd import errors
+    from nncf_amd import weight_lowering as wl
+    w = torch.randn(4, 30, device="cuda")
+    with pytest.raises(errors.InvalidGroupSizeError):
+        wl.compress_weight(w, (1,), _cfg("int4_sym", 16))
+    with pytest.raises(errors.InternalError):
+        wl.do_integer_quantization(w, _cfg("nf4", -1), (1,))
+    with pytest.raises(ValueError):
+        wl.do_integer_quantization(w, _cfg("int4_sym", -1), None)
+    with pytest.raises(errors.UnsupportedBackendError):
+        wl.compress_weight(w.cpu(), (1,), _cfg("int4_sym", -1))
+    with pytest.raises(errors.ValidationError):
+        wl.pack_uint4(torch.zeros(4, dtype=torch.int8, device="cuda"))
+    with pytest.raises(errors.InternalError):
+        wl.get_integer_quantization_error(w, (1,), _cfg("int8_asym", -1), "l1")
+    empty = wl.compress_weight(torch.empty(0, 16, device="cuda"), (1,), _cfg("int8_asym", -1))
+    assert empty.tensor.numel() == 0
+
+
+def test_large_tensor_properties():
+    """Llama-3-8B gate_proj shape: size-independent properties at full size + oracle on a row slice."""
+    from nncf_amd import weight_lowering as wl
+    torch.manual_seed(0)
+    w = (torch.randn(14336, 4096, device="cuda") * 0.02).to(torch.bfloat16)
+    cfg = _cfg("int4_sym", 128)
+    cw = wl.compress_weight(w, (1,), cfg)
+    fused = wl.compress_weight_packed(w, (1,), cfg)
+    assert torch.equal(wl.pack_int4(cw.tensor), fused.tensor)
+    assert torch.equal(wl.unpack_int4(fused.tensor).reshape(cw.tensor.shape), cw.tensor)
+    assert torch.equal(cw.scale, fused.scale)
+    assert int(cw.tensor.min()) == -8 and int(cw.tensor.max()) <= 7
+    # every group attains -8 (the signed-scale convention maps the extreme element to -8)
+    assert bool((cw.tensor.amin(dim=-1) == -8).all())
+    # idempotence: re-quantizing the dequantized weight with the same scale gives the same codes
+    dq = wl.do_integer_dequantization(cw)
+    again = wl.do_integer_quantization(dq, cfg, None, cw.scale)
+    assert torch.equal(again.tensor, cw.tensor)
+    sl = slice(5000, 5064)
+    rc, rs, _ = O.compress_weight(w[sl].float().cpu().numpy(), (1,), "int4_sym", 128)
+    assert_equal_nan(host(cw.tensor[sl]), rc)
+    assert_equal_nan(host(cw.scale[sl]), rs)
