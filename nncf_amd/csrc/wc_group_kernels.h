@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void k_generic(GroupArgs a) {
         par = pol.load(a, g);
     }
     pol.store(a, g, par);
+    int prev_nibble = 0;
     for (int64_t k = 0; k < a.gs; ++k) {
         const int64_t idx = first + k * a.inner;
         int code;
@@ -242,6 +243,11 @@ __global__ __launch_bounds__(256) void k_generic(GroupArgs a) {
         if (a.codes) ((uint8_t*)a.codes)[idx] = (uint8_t)code;
         if (a.values) a.values[idx] = val;
         if (a.dq) a.dq[idx] = pol.dq(code, val, par);
+        if (a.packed) {  // host guarantees inner == 1 and an even group size here: pairs never straddle groups
+            const int nib = pol.nibble(code) & 15;
+            if (k & 1) a.packed[idx >> 1] = (uint8_t)(prev_nibble | (nib << 4));
+            prev_nibble = nib;
+        }
     }
 }
 
@@ -299,7 +305,8 @@ static int run_group_op(GroupArgs a, int pack_bias, const char* what, hipStream_
         return launch_status(what);
     }
     uint8_t* packed = a.packed;
-    a.packed = nullptr;
+    if (packed && a.inner == 1 && (a.gs & 1) == 0) packed = nullptr;  // packed inline by k_generic
+    if (packed) a.packed = nullptr;
     if (packed && !a.codes) {
         set_error("%s: packed output for this layout (unaligned, odd group size or inner>1) needs codes_out too", what);
         return NNCF_AMD_ERR_UNSUPPORTED;

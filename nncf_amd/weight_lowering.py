@@ -147,6 +147,8 @@ def _int_quantize(weight: torch.Tensor, config: WeightCompressionConfig, reducti
         else:
             zp_in, zp_dtype = _per_group(precomputed_zero_point, wv, axis, torch.float32), _lib.ZP_F32
     compute_params = scale_in is None
+    if want_packed and (inner != 1 or r % 2):
+        want_codes = True  # the C ABI packs such layouts from the byte codes (include/nncf_amd_wc.h)
     codes = torch.empty(wv.shape, dtype=torch.uint8 if config.is_asym_mode else torch.int8, device=dev) \
         if want_codes else None
     packed = torch.empty((wv.numel() // 2, 1), dtype=torch.uint8, device=dev) if want_packed else None
@@ -314,6 +316,8 @@ def _float_quantize(weight: torch.Tensor, config: WeightCompressionConfig, reduc
         outer, r, inner = _layout(wv.shape, axis)
         pshape = _param_shape(wv.shape, axis)
     scale_in = _per_group(precomputed_scale, wv, axis, torch.float32)
+    if want_packed and (inner != 1 or r % 2):
+        want_codes = True
     values = torch.empty(wv.shape, dtype=torch.float32, device=dev) if want_values else None
     codes = torch.empty(wv.shape, dtype=torch.uint8, device=dev) if want_codes else None
     packed = torch.empty((wv.numel() // 2, 1), dtype=torch.uint8, device=dev) if want_packed else None
