@@ -90,6 +90,56 @@ __device__ __forceinline__ float lanes_allreduce(float x, Op op) {
     if constexpr (LANES >= 64) x = op(x, __shfl_xor(x, 32, 64));
     return x;
 }
+// v_min3/v_max3 and DPP min/max through inline asm: llvm.minnum on values of unknown provenance (bit-cast
+// loads) is lowered with a v_max x,x canonicalisation per operand in IEEE mode, doubling the VALU cost of
+// the statistics pass.  NaN weights are outside the contract (the reference's int cast of NaN is undefined).
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float max3_abs_raw(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// (lo, hi) <- (min, max) over aligned sets of LANES <= 16 lanes, every lane gets the result.
+// s_nop 1: a DPP read of a VGPR written by the previous VALU instruction needs 2 wait states and hipcc
+// pads nothing inside asm.
+template <int LANES>
+__device__ __forceinline__ void minmax_dpp16(float& lo, float& hi) {
+    static_assert(LANES <= 16, "row-local DPP only");
+    if constexpr (LANES >= 2)
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(lo), "+v"(hi));
+    if constexpr (LANES >= 4)
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(lo), "+v"(hi));
+    if constexpr (LANES >= 8)
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(lo), "+v"(hi));
+    if constexpr (LANES >= 16)
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(lo), "+v"(hi));
+}
+template <int LANES>
+__device__ __forceinline__ void max_dpp16(float& hi) {
+    static_assert(LANES <= 16, "row-local DPP only");
+    if constexpr (LANES >= 2)
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(hi));
+    if constexpr (LANES >= 4)
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(hi));
+    if constexpr (LANES >= 8)
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(hi));
+    if constexpr (LANES >= 16)
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(hi));
+}
+
 struct OpMin {
     __device__ __forceinline__ float operator()(float a, float b) const { return fminf(a, b); }
 };

@@ -75,9 +75,75 @@ struct FloatPolicy {
     __device__ __forceinline__ FloatPolicy(const GroupArgs& a, const float* lds) : lut(lds), mode(a.mode) {}
     __device__ __forceinline__ Stat stat_init() const { return {0.0f}; }
     __device__ __forceinline__ void stat_add(Stat& s, float f) const { s.amax = fmaxf(s.amax, fabsf(f)); }
+    template <int E>
+    __device__ __forceinline__ void stat_add_vec(Stat& s, const float* f) const {
+#pragma unroll
+        for (int i = 0; i < E; i += 2) s.amax = max3_abs_raw(s.amax, f[i], f[i + 1]);
+    }
     template <int L>
     __device__ __forceinline__ void stat_lanes(Stat& s) const {
-        s.amax = lanes_allreduce<L>(s.amax, OpMax());
+        max_dpp16<(L < 16 ? L : 16)>(s.amax);
+        if constexpr (L >= 32) s.amax = fmaxf(s.amax, __shfl_xor(s.amax, 16, 64));
+        if constexpr (L >= 64) s.amax = fmaxf(s.amax, __shfl_xor(s.amax, 32, 64));
+    }
+    template <int E>
+    __device__ __forceinline__ void emit(const GroupArgs& a, const Par& p, const float* f, int64_t v) const {
+        emit_vec<E>(a, *this, p, f, v);
+    }
+    template <int NE, int GPL>
+    __device__ __forceinline__ void emit_lane(const GroupArgs& a, const Par* par, float* f, int64_t e0) const {
+        constexpr int SG = NE / GPL;
+        int code[NE];
+#pragma unroll
+        for (int gi = 0; gi < GPL; ++gi) {
+#pragma unroll
+            for (int i = 0; i < SG; ++i) {
+                float val;
+                quant(f[gi * SG + i], par[gi], code[gi * SG + i], val);
+                f[gi * SG + i] = val;
+            }
+        }
+        if (a.packed) {
+            uint32_t w[NE / 8];
+#pragma unroll
+            for (int j = 0; j < NE / 8; ++j) {
+                w[j] = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w[j] |= (uint32_t)code[8 * j + i] << (4 * i);
+            }
+            uint32_t* dst = (uint32_t*)(a.packed + e0 / 2);
+            if constexpr (NE == 16) *(uint2*)dst = make_uint2(w[0], w[1]);
+            if constexpr (NE == 32) *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        if (a.codes) {
+            uint4* dst = (uint4*)((uint8_t*)a.codes + e0);
+#pragma unroll
+            for (int j = 0; j < NE / 16; ++j) {
+                uint32_t b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    b[q] = (uint32_t)code[16 * j + 4 * q] | ((uint32_t)code[16 * j + 4 * q + 1] << 8) |
+                           ((uint32_t)code[16 * j + 4 * q + 2] << 16) | ((uint32_t)code[16 * j + 4 * q + 3] << 24);
+                dst[j] = make_uint4(b[0], b[1], b[2], b[3]);
+            }
+        }
+        if (a.values) {
+            float4* o = (float4*)(a.values + e0);
+#pragma unroll
+            for (int j = 0; j < NE / 4; ++j) o[j] = make_float4(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]);
+        }
+        if (a.dq) {
+            float4* o = (float4*)(a.dq + e0);
+#pragma unroll
+            for (int gi = 0; gi < GPL; ++gi) {
+                const float sc = par[gi].scale;
+#pragma unroll
+                for (int j = 0; j < SG / 4; ++j) {
+                    const int q = gi * SG + 4 * j;
+                    o[q / 4] = make_float4(f[q] * sc, f[q + 1] * sc, f[q + 2] * sc, f[q + 3] * sc);
+                }
+            }
+        }
     }
     __device__ __forceinline__ void stat_block(Stat& s, float* smem) const {
         s.amax = block_allreduce<4>(s.amax, OpMax(), smem);

@@ -13,8 +13,9 @@
 //   Stat stat_init(); void stat_add(Stat&, float); template<int L> void stat_lanes(Stat&);
 //   void stat_block(Stat&, float* smem16)        block (4 waves) all-reduce
 //   Par compute(const Stat&); Par load(const GroupArgs&, int64 g); void store(const GroupArgs&, int64 g, const Par&)
-//   void quant(float w, const Par&, int& code, float& value)
+//   void quant(float w, const Par&, int& code, float& value)   scalar form (generic kernel)
 //   float dq(int code, float value, const Par&);  int nibble(int code)
+//   template<int E> void stat_add_vec(Stat&, const float*); template<int E> void emit(args, par, f, v)  vector forms
 #pragma once
 #include "wc_common.h"
 
@@ -87,51 +88,97 @@ __device__ __forceinline__ void emit_vec(const GroupArgs& a, const Policy& pol, 
 }
 
 // ------------------------------------------------------------------------------------------------ grouped
-template <typename Policy, int DT, int LPG, int UNROLL>
+// LDS-staged groups.  A wave owns tiles of 64*VPL consecutive 16-byte vectors (VPL KiB).  The tile is brought
+// in by VPL fully coalesced LDS-DMA loads (global_load_lds_dwordx4: no VGPR round trip) into a wave-private
+// LDS image, from which every lane reads VPL *consecutive* vectors (VPL*E elements of one group, or of VPL/VPG
+// whole groups).  So the per-group work (cross-lane reduction, scale / reciprocal / zero point) is amortised over
+// VPL*E elements per lane instead of E, and packed output leaves as one 16-byte store per lane.
+//   LDS image: vector (l, k) (lane l, k-th vector of that lane) sits in 16-byte slot l*VPL + (k ^ ((l>>2)&3));
+//   the XOR spreads the 16 lanes that one ds_read_b128 services together over all 64 banks (conflict free).
+//   The DMA writes slots linearly (slot = u*64 + lane), so the permutation is applied to the global SOURCE
+//   address; one DMA instruction still reads one contiguous KiB.
+// LEAN: compile-time promise that only packed codes + computed parameters are written (the data-free
+// compress path): no uniform output branches.
+constexpr int kVPL = 4;
+
+template <typename Policy, int DT, int VPG, bool LEAN>
 __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
+    constexpr int VPL = kVPL;
     constexpr int E = Elem<DT>::kPerVec;
+    constexpr int NE = VPL * E;                         // elements per lane
+    constexpr int GPL = VPG >= VPL ? 1 : VPL / VPG;     // groups per lane
+    constexpr int LPG = VPG >= VPL ? VPG / VPL : 1;     // lanes per group
+    constexpr int SG = NE / GPL;                        // elements of one group held by one lane
+    static_assert(LPG <= 64, "group must fit in one wave");
+    __shared__ Vec16 stage[4][64 * VPL];
     __shared__ float lds[kPolicyLds];
     Policy::init_shared(lds);
     __syncthreads();
     const Policy pol(a, lds);
-    const int64_t nvec = a.n_groups * LPG;
-    const Vec16* __restrict__ wv = (const Vec16*)a.w;
-    const int64_t step = (int64_t)gridDim.x * 256 * UNROLL;
+    GroupArgs o = a;
+    if constexpr (LEAN) {
+        o.codes = nullptr;
+        o.values = nullptr;
+        o.dq = nullptr;
+        o.scale_in = nullptr;
+    }
+    const int64_t nvec = a.n_groups * VPG;
     const int lane = threadIdx.x & 63;
-    const int64_t wave_global = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-    // a wave covers UNROLL consecutive KiB per iteration; `base` is wave-uniform
-    for (int64_t base = wave_global * 64 * UNROLL; base < nvec; base += step) {
-        Vec16 raw[UNROLL];
+    const int wave = threadIdx.x >> 6;
+    Vec16* my = stage[wave];
+    const Vec16* __restrict__ wv = (const Vec16*)a.w;
+    const int64_t n_tiles = (nvec + 64 * VPL - 1) / (64 * VPL);
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wave_count = (int64_t)gridDim.x * 4;
+    // source permutation of the DMA (see above): slot s = u*64 + lane holds vector (l = s>>2, k = (s&3)^((s>>4)&3))
+    int src_off[VPL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t v = base + u * 64 + lane;
-            if (v < nvec) {
-                raw[u] = wv[v];
-            } else {
-                raw[u].w[0] = raw[u].w[1] = raw[u].w[2] = raw[u].w[3] = 0u;
-            }
+    for (int u = 0; u < VPL; ++u) {
+        const int sidx = u * 64 + lane;
+        src_off[u] = (sidx & ~3) + ((sidx & 3) ^ ((sidx >> 4) & 3));
+    }
+    const int rot = (lane >> 2) & 3;
+    for (int64_t tile = wave_global; tile < n_tiles; tile += wave_count) {
+        const int64_t base = tile * (64 * VPL);
+        const bool full = base + 64 * VPL <= nvec;  // wave-uniform
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) {
+            int64_t v = base + src_off[u];
+            if (!full) v = v < nvec ? v : nvec - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wv + v),
+                                             (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float f[NE];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t v = base + u * 64 + lane;
-            const bool live = v < nvec;
-            const int64_t g = v / LPG;
-            float f[E];
-            unpack<DT>(raw[u], f);
-            typename Policy::Par par;
-            if (a.scale_in == nullptr) {
+        for (int k = 0; k < VPL; ++k) {
+            const Vec16 raw = my[lane * VPL + (k ^ rot)];
+            unpack<DT>(raw, f + k * E);
+        }
+        // the LDS image is consumed: the next iteration's DMA may overwrite it only after these reads returned
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t v0 = base + (int64_t)lane * VPL;  // first vector of this lane
+        const bool live = full || v0 < nvec;            // host guarantees nvec % VPL == 0: lanes are all-or-nothing
+        const int64_t g0 = GPL > 1 ? v0 / VPG : v0 / VPG;
+        typename Policy::Par par[GPL];
+        if (LEAN || o.scale_in == nullptr) {
+#pragma unroll
+            for (int gi = 0; gi < GPL; ++gi) {
                 typename Policy::Stat st = pol.stat_init();
+                pol.template stat_add_vec<SG>(st, f + gi * SG);
+                if constexpr (LPG > 1) pol.template stat_lanes<LPG>(st);  // all 64 lanes take part
+                par[gi] = pol.compute(st);
+            }
+        } else {
 #pragma unroll
-                for (int i = 0; i < E; ++i) pol.stat_add(st, f[i]);
-                pol.template stat_lanes<LPG>(st);  // all 64 lanes take part (dead lanes carry zeros)
-                par = pol.compute(st);
-            } else {
-                par = pol.load(a, live ? g : 0);
+            for (int gi = 0; gi < GPL; ++gi) par[gi] = pol.load(o, live ? g0 + gi : 0);
+        }
+        if (live) {
+            if ((lane & (LPG - 1)) == 0) {
+#pragma unroll
+                for (int gi = 0; gi < GPL; ++gi) pol.store(o, g0 + gi, par[gi]);
             }
-            if (live) {
-                if ((lane & (LPG - 1)) == 0) pol.store(a, g, par);
-                emit_vec<E>(a, pol, par, f, v);
-            }
+            pol.template emit_lane<NE, GPL>(o, par, f, v0 * E);
         }
     }
 }
@@ -172,15 +219,13 @@ __global__ __launch_bounds__(256) void k_row(GroupArgs a, int64_t vpg) {
                     if (j < vpg) {
                         float f[E];
                         unpack<DT>(keep[k], f);
-#pragma unroll
-                        for (int i = 0; i < E; ++i) pol.stat_add(st, f[i]);
+                        pol.template stat_add_vec<E>(st, f);
                     }
                 }
                 for (int64_t j = t + (int64_t)KEEP * TEAM; j < vpg; j += TEAM) {
                     float f[E];
                     unpack<DT>(wv[vbase + j], f);
-#pragma unroll
-                    for (int i = 0; i < E; ++i) pol.stat_add(st, f[i]);
+                    pol.template stat_add_vec<E>(st, f);
                 }
             }
             if constexpr (TEAM == 64) {
@@ -200,13 +245,13 @@ __global__ __launch_bounds__(256) void k_row(GroupArgs a, int64_t vpg) {
             if (j < vpg) {
                 float f[E];
                 unpack<DT>(keep[k], f);
-                emit_vec<E>(a, pol, par, f, vbase + j);
+                pol.template emit<E>(a, par, f, vbase + j);
             }
         }
         for (int64_t j = t + (int64_t)KEEP * TEAM; j < vpg; j += TEAM) {
             float f[E];
             unpack<DT>(wv[vbase + j], f);
-            emit_vec<E>(a, pol, par, f, vbase + j);
+            pol.template emit<E>(a, par, f, vbase + j);
         }
     }
 }
@@ -266,12 +311,19 @@ static inline int clamp_grid(int64_t blocks) {
     return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
-template <typename Policy, int DT, int LPG>
+template <typename Policy, int DT, int VPG>
 static void launch_grouped(const GroupArgs& a, hipStream_t s) {
-    constexpr int U = 4;
-    const int64_t nvec = a.n_groups * LPG;
-    const int64_t blocks = (nvec + 256 * U - 1) / (256 * U);
-    hipLaunchKernelGGL((k_grouped<Policy, DT, LPG, U>), dim3(clamp_grid(blocks)), dim3(256), 0, s, a);
+    const int64_t nvec = a.n_groups * VPG;
+    const int64_t tiles = (nvec + 64 * kVPL - 1) / (64 * kVPL);
+    // 256 CUs x 8 resident blocks; more tiles than that are strided over by the resident waves
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    const bool lean = a.packed && a.scale_out && !a.scale_in && !a.codes && !a.values && !a.dq;
+    if (lean) {
+        hipLaunchKernelGGL((k_grouped<Policy, DT, VPG, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((k_grouped<Policy, DT, VPG, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
 }
 
 static inline bool is16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
@@ -285,7 +337,8 @@ static int run_group_op(GroupArgs a, int pack_bias, const char* what, hipStream_
     const int64_t group_bytes = a.gs * EB;
     if (a.inner == 1 && aligned && group_bytes % 16 == 0) {
         const int64_t vpg = group_bytes / 16;
-        if (vpg <= 64 && (vpg & (vpg - 1)) == 0) {
+        const bool whole_lanes = (a.n_groups * vpg) % kVPL == 0;  // k_grouped: a lane is all live or all dead
+        if (vpg <= 256 && (vpg & (vpg - 1)) == 0 && whole_lanes) {
             switch ((int)vpg) {
                 case 1: launch_grouped<Policy, DT, 1>(a, s); break;
                 case 2: launch_grouped<Policy, DT, 2>(a, s); break;
@@ -293,10 +346,13 @@ static int run_group_op(GroupArgs a, int pack_bias, const char* what, hipStream_
                 case 8: launch_grouped<Policy, DT, 8>(a, s); break;
                 case 16: launch_grouped<Policy, DT, 16>(a, s); break;
                 case 32: launch_grouped<Policy, DT, 32>(a, s); break;
-                default: launch_grouped<Policy, DT, 64>(a, s); break;
+                case 64: launch_grouped<Policy, DT, 64>(a, s); break;
+                case 128: launch_grouped<Policy, DT, 128>(a, s); break;
+                default: launch_grouped<Policy, DT, 256>(a, s); break;
             }
             return launch_status(what);
         }
+        if (vpg < kVPL) goto generic_path;
         if (vpg <= 512) {
             hipLaunchKernelGGL((k_row<Policy, DT, 64, 8>), dim3(clamp_grid((a.n_groups + 3) / 4)), dim3(256), 0, s, a, vpg);
         } else {
@@ -304,6 +360,7 @@ static int run_group_op(GroupArgs a, int pack_bias, const char* what, hipStream_
         }
         return launch_status(what);
     }
+generic_path:
     uint8_t* packed = a.packed;
     if (packed && a.inner == 1 && (a.gs & 1) == 0) packed = nullptr;  // packed inline by k_generic
     if (packed) a.packed = nullptr;
