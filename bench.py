@@ -107,11 +107,9 @@ class Job:
                                                  self.c_out if four else None, self.c_scale, self.c_zp, s)
             self._lib.check(st)
         else:
-            for i, w in enumerate(self.weights):
-                st = L.nncf_amd_float_quantize(self.c_w[i], self._lib.BF16, w.shape[0], w.shape[1], 1, self.gs,
-                                               self._lib.MODE_ID[self.mode], None, None, None, self.c_out[i],
-                                               self.c_scale[i], None, None, s)
-                self._lib.check(st)
+            st = L.nncf_amd_float_quantize_batched(self.n, self.c_w, self._lib.BF16, self.c_rows, self.c_cols, self.gs,
+                                                   self._lib.MODE_ID[self.mode], self.c_out, self.c_scale, None, s)
+            self._lib.check(st)
 
 
 def cpu_baseline(geometry, mode, gs, budget_s=12.0):

@@ -149,6 +149,13 @@ int nncf_amd_float_quantize(const void* weight, int w_dtype, int64_t outer, int6
                             uint8_t* codes_out, uint8_t* packed_out, float* scale_out, uint8_t* scale_e8m0_out,
                             float* dq_out, void* stream);
 
+/* Batched data-free form (packed 4-bit codes + scales [+ E8M0 bytes]); arrays are HOST arrays of device pointers,
+ * as in nncf_amd_int_quantize_batched.  scale_e8m0_out_host may be NULL. */
+int nncf_amd_float_quantize_batched(int n, const void* const* weights_host, int w_dtype, const int64_t* rows_host,
+                                    const int64_t* cols_host, int64_t group_size, int mode,
+                                    uint8_t* const* packed_out_host, float* const* scale_out_host,
+                                    uint8_t* const* scale_e8m0_out_host, void* stream);
+
 /*
  * Activation-statistics reducers over x = [batch, tokens, hidden] (contiguous, dtype x_dtype).
  * Replace TensorReducerBase._reduce_out_of_place of

@@ -39,6 +39,9 @@ SIGNATURES = {
     "nncf_amd_unpack_i4": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "nncf_amd_float_quantize": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nncf_amd_float_quantize_batched": (c_int, [c_int, POINTER(c_void_p), c_int, POINTER(c_int64), POINTER(c_int64),
+                                                c_int64, c_int, POINTER(c_void_p), POINTER(c_void_p),
+                                                POINTER(c_void_p), c_void_p]),
 }
 PENDING = {
     "nncf_amd_reduce_workspace": (c_size_t, [c_int64, c_int64, c_int64]),

@@ -7,6 +7,8 @@
 // equals searchsorted(centers, n, side='left') of weight_lowering.py:574 for every float n, and the e2m1
 // tie rule of weight_lowering.py:577-583 is then applied literally on the two neighbouring quantiles.
 #include "wc_e8m0_table.h"
+#include <vector>
+
 #include "wc_group_kernels.h"
 
 namespace wc {
@@ -231,4 +233,45 @@ extern "C" int nncf_amd_float_quantize(const void* weight, int w_dtype, int64_t 
     a.mode = mode;
     if (mode == NNCF_AMD_NF4) return run_group_op_dtype<FloatPolicy<true>>(w_dtype, a, 0, "float_quantize", (hipStream_t)stream);
     return run_group_op_dtype<FloatPolicy<false>>(w_dtype, a, 0, "float_quantize", (hipStream_t)stream);
+}
+
+extern "C" int nncf_amd_float_quantize_batched(int n, const void* const* weights_host, int w_dtype,
+                                               const int64_t* rows_host, const int64_t* cols_host,
+                                               int64_t group_size, int mode, uint8_t* const* packed_out_host,
+                                               float* const* scale_out_host, uint8_t* const* scale_e8m0_out_host,
+                                               void* stream) {
+    using namespace wc;
+    if (n < 0 || (n > 0 && (!weights_host || !rows_host || !cols_host || !packed_out_host || !scale_out_host))) {
+        set_error("float_quantize_batched: bad descriptor arrays");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (mode != NNCF_AMD_NF4 && mode != NNCF_AMD_MXFP4 && mode != NNCF_AMD_FP4) {
+        set_error("float_quantize_batched: mode %d is not a float codebook mode", mode);
+        return NNCF_AMD_ERR_MODE;
+    }
+    if (scale_e8m0_out_host && mode != NNCF_AMD_MXFP4) {
+        set_error("float_quantize_batched: scale_e8m0_out is for MXFP4 only");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (n > 0 && (w_dtype == NNCF_AMD_F32 || w_dtype == NNCF_AMD_F16 || w_dtype == NNCF_AMD_BF16)) {
+        std::vector<BatchItem> items(n);
+        for (int i = 0; i < n; ++i)
+            items[i] = {weights_host[i], rows_host[i], cols_host[i], packed_out_host[i], scale_out_host[i],
+                        scale_e8m0_out_host ? (void*)scale_e8m0_out_host[i] : nullptr};
+        int vpg;
+        if (batch_fits<FloatPolicy<true>>(w_dtype, items.data(), n, group_size, &vpg)) {
+            if (mode == NNCF_AMD_NF4)
+                return run_batch<FloatPolicy<true>>(w_dtype, items.data(), n, vpg, mode, "float_quantize_batched",
+                                                    (hipStream_t)stream);
+            return run_batch<FloatPolicy<false>>(w_dtype, items.data(), n, vpg, mode, "float_quantize_batched",
+                                                 (hipStream_t)stream);
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        int st = nncf_amd_float_quantize(weights_host[i], w_dtype, rows_host[i], cols_host[i], 1, group_size, mode, nullptr,
+                                         nullptr, nullptr, packed_out_host[i], scale_out_host[i],
+                                         scale_e8m0_out_host ? scale_e8m0_out_host[i] : nullptr, nullptr, stream);
+        if (st != NNCF_AMD_OK) return st;
+    }
+    return NNCF_AMD_OK;
 }

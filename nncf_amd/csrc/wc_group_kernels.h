@@ -17,6 +17,8 @@
 //   float dq(int code, float value, const Par&);  int nibble(int code)
 //   template<int E> void stat_add_vec(Stat&, const float*); template<int E> void emit(args, par, f, v)  vector forms
 #pragma once
+#include <stdlib.h>
+
 #include "wc_common.h"
 
 namespace wc {
@@ -38,6 +40,8 @@ struct GroupArgs {
     int64_t inner;
     int mode;
 };
+
+static inline bool is16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 constexpr int kPolicyLds = 128;  // floats of block-shared table space handed to a policy
 
@@ -109,8 +113,9 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
     constexpr int GPL = VPG >= VPL ? 1 : VPL / VPG;     // groups per lane
     constexpr int LPG = VPG >= VPL ? VPG / VPL : 1;     // lanes per group
     constexpr int SG = NE / GPL;                        // elements of one group held by one lane
+    constexpr int TILE = 64 * VPL;                      // vectors per tile
     static_assert(LPG <= 64, "group must fit in one wave");
-    __shared__ Vec16 stage[4][64 * VPL];
+    __shared__ Vec16 stage[4][TILE];
     __shared__ float lds[kPolicyLds];
     Policy::init_shared(lds);
     __syncthreads();
@@ -124,30 +129,42 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
     }
     const int64_t nvec = a.n_groups * VPG;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile bases stay in SGPRs
     Vec16* my = stage[wave];
-    const Vec16* __restrict__ wv = (const Vec16*)a.w;
-    const int64_t n_tiles = (nvec + 64 * VPL - 1) / (64 * VPL);
+    const char* __restrict__ wbytes = (const char*)a.w;
+    const int64_t n_tiles = (nvec + TILE - 1) / TILE;
     const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
     const int64_t wave_count = (int64_t)gridDim.x * 4;
     // source permutation of the DMA (see above): slot s = u*64 + lane holds vector (l = s>>2, k = (s&3)^((s>>4)&3))
-    int src_off[VPL];
+    uint32_t src_off[VPL];  // byte offset inside the tile
 #pragma unroll
     for (int u = 0; u < VPL; ++u) {
         const int sidx = u * 64 + lane;
-        src_off[u] = (sidx & ~3) + ((sidx & 3) ^ ((sidx >> 4) & 3));
+        src_off[u] = (uint32_t)((sidx & ~3) + ((sidx & 3) ^ ((sidx >> 4) & 3))) * 16u;
     }
     const int rot = (lane >> 2) & 3;
-    for (int64_t tile = wave_global; tile < n_tiles; tile += wave_count) {
-        const int64_t base = tile * (64 * VPL);
-        const bool full = base + 64 * VPL <= nvec;  // wave-uniform
+    auto issue_dma = [&](int64_t tile) {
+        const int64_t base = tile * TILE;
+        const char* tbase = wbytes + base * 16;  // wave-uniform
+        if (base + TILE <= nvec) {
 #pragma unroll
-        for (int u = 0; u < VPL; ++u) {
-            int64_t v = base + src_off[u];
-            if (!full) v = v < nvec ? v : nvec - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wv + v),
-                                             (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
+            for (int u = 0; u < VPL; ++u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + src_off[u]),
+                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
+        } else {
+            const uint32_t last = (uint32_t)(nvec - base - 1) * 16u;  // partial tile: clamp to the last valid vector
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) {
+                const uint32_t off = src_off[u] < last ? src_off[u] : last;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + off),
+                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
+            }
         }
+    };
+    int64_t tile = wave_global;
+    if (tile < n_tiles) issue_dma(tile);
+    for (; tile < n_tiles; tile += wave_count) {
+        const int64_t base = tile * TILE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float f[NE];
 #pragma unroll
@@ -155,11 +172,12 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
             const Vec16 raw = my[lane * VPL + (k ^ rot)];
             unpack<DT>(raw, f + k * E);
         }
-        // the LDS image is consumed: the next iteration's DMA may overwrite it only after these reads returned
+        // the LDS image now lives in registers: refill it with this wave's next tile while this one is processed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tile + wave_count < n_tiles) issue_dma(tile + wave_count);
         const int64_t v0 = base + (int64_t)lane * VPL;  // first vector of this lane
-        const bool live = full || v0 < nvec;            // host guarantees nvec % VPL == 0: lanes are all-or-nothing
-        const int64_t g0 = GPL > 1 ? v0 / VPG : v0 / VPG;
+        const bool live = v0 < nvec;                    // host guarantees nvec % VPL == 0: lanes are all-or-nothing
+        const int64_t g0 = v0 / VPG;
         typename Policy::Par par[GPL];
         if (LEAN || o.scale_in == nullptr) {
 #pragma unroll
@@ -181,6 +199,218 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
             pol.template emit_lane<NE, GPL>(o, par, f, v0 * E);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ grouped, multi-tensor
+// The data-free compress path over MANY tensors in one launch: a launch boundary costs ~4 us of ramp-up, drain and
+// dispatch on MI355X, as much as compressing an 8 MB tensor, so per-tensor launches cap a whole-model pass well
+// below the HBM rate.  Tensors are cut into the same 64*VPL-vector tiles; tile ids run through all tensors of the
+// batch (tile_start = prefix sums) and the resident waves stride over them, prefetching their next tile by LDS-DMA
+// while they work on the current one.  Always "lean": packed codes + computed parameters only.
+constexpr int kMaxBatch = 48;
+struct BatchArgs {
+    int n;
+    int mode;
+    int64_t tile_start[kMaxBatch + 1];
+    int64_t nvec[kMaxBatch];
+    const void* w[kMaxBatch];
+    uint8_t* packed[kMaxBatch];
+    float* scale[kMaxBatch];
+    void* aux[kMaxBatch];  // int32 zero points (asymmetric integer modes) or uint8 E8M0 scales (MXFP4); may be NULL
+};
+
+template <typename Policy, int DT, int VPG>
+__global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
+    constexpr int VPL = kVPL;
+    constexpr int E = Elem<DT>::kPerVec;
+    constexpr int NE = VPL * E;
+    constexpr int GPL = VPG >= VPL ? 1 : VPL / VPG;
+    constexpr int LPG = VPG >= VPL ? VPG / VPL : 1;
+    constexpr int SG = NE / GPL;
+    constexpr int TILE = 64 * VPL;
+    __shared__ Vec16 stage[4][TILE];
+    __shared__ float lds[kPolicyLds];
+    Policy::init_shared(lds);
+    __syncthreads();
+    GroupArgs o = {};
+    o.mode = b.mode;
+    const Policy pol(o, lds);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Vec16* my = stage[wave];
+    const int64_t total = b.tile_start[b.n];
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wave_count = (int64_t)gridDim.x * 4;
+    uint32_t src_off[VPL];
+#pragma unroll
+    for (int u = 0; u < VPL; ++u) {
+        const int sidx = u * 64 + lane;
+        src_off[u] = (uint32_t)((sidx & ~3) + ((sidx & 3) ^ ((sidx >> 4) & 3))) * 16u;
+    }
+    const int rot = (lane >> 2) & 3;
+    auto issue_dma = [&](int64_t t, int i) {
+        const int64_t base = (t - b.tile_start[i]) * TILE;
+        const int64_t nvec = b.nvec[i];
+        const char* tbase = (const char*)b.w[i] + base * 16;  // wave-uniform
+        if (base + TILE <= nvec) {
+#pragma unroll
+            for (int u = 0; u < VPL; ++u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + src_off[u]),
+                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
+        } else {
+            const uint32_t last = (uint32_t)(nvec - base - 1) * 16u;
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) {
+                const uint32_t off = src_off[u] < last ? src_off[u] : last;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + off),
+                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
+            }
+        }
+    };
+    int64_t t = wave_global;
+    int i = 0;
+    if (t < total) {
+        while (t >= b.tile_start[i + 1]) ++i;
+        issue_dma(t, i);
+    }
+    for (; t < total; t += wave_count) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float f[NE];
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const Vec16 raw = my[lane * VPL + (k ^ rot)];
+            unpack<DT>(raw, f + k * E);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t tn = t + wave_count;
+        int in = i;
+        if (tn < total) {
+            while (tn >= b.tile_start[in + 1]) ++in;
+            issue_dma(tn, in);
+        }
+        const int64_t base = (t - b.tile_start[i]) * TILE;
+        const int64_t nvec = b.nvec[i];
+        o.packed = b.packed[i];
+        o.scale_out = b.scale[i];
+        o.zp_out = (int32_t*)b.aux[i];
+        o.e8m0_out = (uint8_t*)b.aux[i];
+        const int64_t v0 = base + (int64_t)lane * VPL;
+        const bool live = v0 < nvec;
+        const int64_t g0 = v0 / VPG;
+        typename Policy::Par par[GPL];
+#pragma unroll
+        for (int gi = 0; gi < GPL; ++gi) {
+            typename Policy::Stat st = pol.stat_init();
+            pol.template stat_add_vec<SG>(st, f + gi * SG);
+            if constexpr (LPG > 1) pol.template stat_lanes<LPG>(st);
+            par[gi] = pol.compute(st);
+        }
+        if (live) {
+            if ((lane & (LPG - 1)) == 0) {
+#pragma unroll
+                for (int gi = 0; gi < GPL; ++gi) pol.store(o, g0 + gi, par[gi]);
+            }
+            pol.template emit_lane<NE, GPL>(o, par, f, v0 * E);
+        }
+        i = in;
+    }
+}
+
+template <typename Policy, int DT, int VPG>
+static void launch_batch(const BatchArgs& b, hipStream_t s) {
+    const int64_t tiles = b.tile_start[b.n];
+    int64_t blocks = (tiles + 3) / 4;
+    static const int64_t cap = getenv("NNCF_AMD_GRID_CAP") ? atoll(getenv("NNCF_AMD_GRID_CAP")) : 2048;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_grouped_batch<Policy, DT, VPG>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+}
+
+template <typename Policy, int DT>
+static bool dispatch_batch(int vpg, const BatchArgs& b, hipStream_t s) {
+    switch (vpg) {
+        case 1: launch_batch<Policy, DT, 1>(b, s); return true;
+        case 2: launch_batch<Policy, DT, 2>(b, s); return true;
+        case 4: launch_batch<Policy, DT, 4>(b, s); return true;
+        case 8: launch_batch<Policy, DT, 8>(b, s); return true;
+        case 16: launch_batch<Policy, DT, 16>(b, s); return true;
+        case 32: launch_batch<Policy, DT, 32>(b, s); return true;
+        case 64: launch_batch<Policy, DT, 64>(b, s); return true;
+        case 128: launch_batch<Policy, DT, 128>(b, s); return true;
+        case 256: launch_batch<Policy, DT, 256>(b, s); return true;
+        default: return false;
+    }
+}
+
+// One tensor of a data-free batch.  aux: int32 zero points / uint8 E8M0 scales / NULL.
+struct BatchItem {
+    const void* w;
+    int64_t rows, cols;
+    uint8_t* packed;
+    float* scale;
+    void* aux;
+};
+
+// Queues a whole batch with as few launches as possible; returns false if an item does not fit the grouped
+// kernel (unaligned pointers, group bytes not a power-of-two multiple of 16 up to 4 KiB, ragged lanes), in which
+// case the caller runs that batch tensor by tensor.
+template <typename Policy>
+static bool batch_fits(int w_dtype, const BatchItem* items, int n, int64_t group_size, int* vpg_out) {
+    const int eb = w_dtype == NNCF_AMD_F32 ? 4 : 2;
+    int vpg = -1;
+    for (int i = 0; i < n; ++i) {
+        const int64_t gs = group_size == -1 ? items[i].cols : group_size;
+        if (gs <= 0 || items[i].rows <= 0 || items[i].cols % gs != 0) return false;
+        const int64_t gb = gs * eb;
+        if (gb % 16 != 0) return false;
+        const int64_t v = gb / 16;
+        if (v > 256 || (v & (v - 1)) != 0) return false;
+        if (vpg != -1 && vpg != (int)v) return false;
+        vpg = (int)v;
+        const int64_t nvec = items[i].rows * items[i].cols * eb / 16;
+        if (nvec % kVPL != 0) return false;
+        if (!is16(items[i].w) || !items[i].packed || !is16(items[i].packed) || !items[i].scale) return false;
+    }
+    *vpg_out = vpg;
+    return n > 0;
+}
+
+template <typename Policy>
+static int run_batch(int w_dtype, const BatchItem* items, int n, int vpg, int mode, const char* what, hipStream_t s) {
+    const int eb = w_dtype == NNCF_AMD_F32 ? 4 : 2;
+    for (int first = 0; first < n; first += kMaxBatch) {
+        BatchArgs b = {};
+        b.n = n - first < kMaxBatch ? n - first : kMaxBatch;
+        b.mode = mode;
+        int64_t acc = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const BatchItem& it = items[first + j];
+            const int64_t nvec = it.rows * it.cols * eb / 16;
+            b.tile_start[j] = acc;
+            acc += (nvec + 64 * kVPL - 1) / (64 * kVPL);
+            b.nvec[j] = nvec;
+            b.w[j] = it.w;
+            b.packed[j] = it.packed;
+            b.scale[j] = it.scale;
+            b.aux[j] = it.aux;
+        }
+        b.tile_start[b.n] = acc;
+        bool ok;
+        switch (w_dtype) {
+            case NNCF_AMD_F32: ok = dispatch_batch<Policy, NNCF_AMD_F32>(vpg, b, s); break;
+            case NNCF_AMD_F16: ok = dispatch_batch<Policy, NNCF_AMD_F16>(vpg, b, s); break;
+            case NNCF_AMD_BF16: ok = dispatch_batch<Policy, NNCF_AMD_BF16>(vpg, b, s); break;
+            default:
+                set_error("%s: unsupported weight dtype %d", what, w_dtype);
+                return NNCF_AMD_ERR_DTYPE;
+        }
+        if (!ok) {
+            set_error("%s: internal dispatch error (vpg %d)", what, vpg);
+            return NNCF_AMD_ERR_UNSUPPORTED;
+        }
+        int st = launch_status(what);
+        if (st != NNCF_AMD_OK) return st;
+    }
+    return NNCF_AMD_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ row
@@ -317,16 +547,25 @@ static void launch_grouped(const GroupArgs& a, hipStream_t s) {
     const int64_t tiles = (nvec + 64 * kVPL - 1) / (64 * kVPL);
     // 256 CUs x 8 resident blocks; more tiles than that are strided over by the resident waves
     int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    static const int64_t cap = getenv("NNCF_AMD_GRID_CAP") ? atoll(getenv("NNCF_AMD_GRID_CAP")) : 2048;
+    if (blocks > cap) blocks = cap;
     const bool lean = a.packed && a.scale_out && !a.scale_in && !a.codes && !a.values && !a.dq;
     if (lean) {
-        hipLaunchKernelGGL((k_grouped<Policy, DT, VPG, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        BatchArgs b = {};
+        b.n = 1;
+        b.mode = a.mode;
+        b.tile_start[0] = 0;
+        b.tile_start[1] = tiles;
+        b.nvec[0] = nvec;
+        b.w[0] = a.w;
+        b.packed[0] = a.packed;
+        b.scale[0] = a.scale_out;
+        b.aux[0] = a.zp_out ? (void*)a.zp_out : (void*)a.e8m0_out;
+        hipLaunchKernelGGL((k_grouped_batch<Policy, DT, VPG>), dim3((unsigned)blocks), dim3(256), 0, s, b);
     } else {
         hipLaunchKernelGGL((k_grouped<Policy, DT, VPG, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     }
 }
-
-static inline bool is16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 // pack_bias: added to byte codes before nibble packing on the generic path (8 for INT4_SYM)
 template <typename Policy, int DT>

@@ -4,6 +4,8 @@
 // IEEE divide -> add -> round-half-even -> clip, and the stores the caller asked for (unpacked codes,
 // nibble-packed codes, scale, zero point, dequantized fp32).  HBM-bound by construction: every input byte
 // is read once, every output byte written once.  Kernel skeletons: wc_group_kernels.h.
+#include <vector>
+
 #include "wc_group_kernels.h"
 
 namespace wc {
@@ -302,16 +304,35 @@ extern "C" int nncf_amd_int_quantize_batched(int n, const void* const* weights_h
                                              const int64_t* rows_host, const int64_t* cols_host, int64_t group_size,
                                              int mode, void* const* codes_out_host, uint8_t* const* packed_out_host,
                                              float* const* scale_out_host, int32_t* const* zp_out_host, void* stream) {
+    using namespace wc;
     if (n < 0 || (n > 0 && (!weights_host || !rows_host || !cols_host))) {
-        wc::set_error("int_quantize_batched: bad descriptor arrays");
+        set_error("int_quantize_batched: bad descriptor arrays");
         return NNCF_AMD_ERR_BAD_ARG;
     }
+    if (mode < NNCF_AMD_INT8_ASYM || mode > NNCF_AMD_INT4_SYM) {
+        set_error("int_quantize_batched: mode %d is not an integer mode", mode);
+        return NNCF_AMD_ERR_MODE;
+    }
+    const IntMode m = int_mode(mode);
+    // one multi-tensor launch per 48 tensors when every tensor takes the packed 4-bit grouped path
+    if (n > 0 && m.bits == 4 && packed_out_host && scale_out_host && !codes_out_host && (!m.asym || zp_out_host) &&
+        (w_dtype == NNCF_AMD_F32 || w_dtype == NNCF_AMD_F16 || w_dtype == NNCF_AMD_BF16)) {
+        std::vector<BatchItem> items(n);
+        for (int i = 0; i < n; ++i)
+            items[i] = {weights_host[i], rows_host[i], cols_host[i], packed_out_host[i], scale_out_host[i],
+                        m.asym ? (void*)zp_out_host[i] : nullptr};
+        int vpg;
+        bool fits = batch_fits<IntPolicy>(w_dtype, items.data(), n, group_size, &vpg);
+        if (fits && m.asym)
+            for (int i = 0; i < n; ++i) fits = fits && items[i].aux != nullptr;
+        if (fits) return run_batch<IntPolicy>(w_dtype, items.data(), n, vpg, mode, "int_quantize_batched", (hipStream_t)stream);
+    }
     for (int i = 0; i < n; ++i) {
-        int st = wc::int_quantize_impl(weights_host[i], w_dtype, rows_host[i], cols_host[i], 1, group_size, mode, nullptr,
-                                       nullptr, NNCF_AMD_ZP_NONE, codes_out_host ? codes_out_host[i] : nullptr,
-                                       packed_out_host ? packed_out_host[i] : nullptr,
-                                       scale_out_host ? scale_out_host[i] : nullptr,
-                                       zp_out_host ? zp_out_host[i] : nullptr, nullptr, (hipStream_t)stream);
+        int st = int_quantize_impl(weights_host[i], w_dtype, rows_host[i], cols_host[i], 1, group_size, mode, nullptr,
+                                   nullptr, NNCF_AMD_ZP_NONE, codes_out_host ? codes_out_host[i] : nullptr,
+                                   packed_out_host ? packed_out_host[i] : nullptr,
+                                   scale_out_host ? scale_out_host[i] : nullptr, zp_out_host ? zp_out_host[i] : nullptr,
+                                   nullptr, (hipStream_t)stream);
         if (st != NNCF_AMD_OK) return st;
     }
     return NNCF_AMD_OK;

@@ -406,3 +406,67 @@ def compress_weight_packed(weight: torch.Tensor, reduction_axes: ReductionAxes, 
     _, _, packed, _, scale, _ = _float_quantize(weight, config, reduction_axes, scale, want_values=False,
                                                 want_packed=True)
     return CompressedWeight(packed, scale)
+
+
+def compress_weights_packed_batched(weights, config: WeightCompressionConfig, want_e8m0: bool = False):
+    """Data-free compression of MANY 2-D [out, in] weights (reduction along the last axis) in as few launches as
+    possible: the lowering part of PTWeightCompressionAlgoBackend.transform_model's per-weight loop
+    (torch_backend.py:442-477) + pack_weight.  Returns a list of CompressedWeight with
+    tensor = nibble-packed uint8 [N/2, 1] (4-bit modes) or int8/uint8 codes (8-bit), scale fp32 [out, G, 1],
+    zero_point int32 (asymmetric) and, for MXFP4 with want_e8m0, codebook = uint8 E8M0 scale bytes."""
+    import ctypes
+
+    config = as_config(config)
+    if not weights:
+        return []
+    ws = [_prep_weight(w, "compress_weights_packed_batched") for w in weights]
+    dev, dt = ws[0].device, ws[0].dtype
+    for w in ws:
+        if w.ndim != 2 or w.device != dev or w.dtype != dt:
+            raise InternalError("compress_weights_packed_batched: 2-D weights of one dtype on one device expected")
+        if config.group_size != -1 and w.shape[1] % config.group_size != 0:
+            msg = f"Channel size {w.shape[1]} should be divisible by size of group {config.group_size}."
+            raise InvalidGroupSizeError(msg)
+    n = len(ws)
+    four = config.num_bits == 4
+    asym = config.is_integer and config.is_asym_mode
+    outs, scales, auxs = [], [], []
+    for w in ws:
+        o, i = w.shape
+        g = config.group_size if config.group_size != -1 else i
+        pshape = (o, i // g, 1) if config.group_size != -1 else (o, 1)
+        gshape = (o, i // g, g) if config.group_size != -1 else (o, i)
+        if four:
+            outs.append(torch.empty((o * i // 2, 1), dtype=torch.uint8, device=dev))
+        else:
+            outs.append(torch.empty(gshape, dtype=torch.uint8 if asym else torch.int8, device=dev))
+        scales.append(torch.empty(pshape, dtype=torch.float32, device=dev))
+        if asym:
+            auxs.append(torch.empty(pshape, dtype=torch.int32, device=dev))
+        elif want_e8m0 and config.mode.value == "mxfp4":
+            auxs.append(torch.empty(pshape, dtype=torch.uint8, device=dev))
+        else:
+            auxs.append(None)
+    VP, I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+    c_w = VP(*[w.data_ptr() for w in ws])
+    c_rows, c_cols = I64(*[w.shape[0] for w in ws]), I64(*[w.shape[1] for w in ws])
+    c_out, c_scale = VP(*[t.data_ptr() for t in outs]), VP(*[t.data_ptr() for t in scales])
+    c_aux = VP(*[t.data_ptr() if t is not None else None for t in auxs]) if any(a is not None for a in auxs) else None
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        stream = _lib.stream_of(ws[0])
+        if config.is_integer:
+            st = L.nncf_amd_int_quantize_batched(n, c_w, _lib.dtype_id(ws[0]), c_rows, c_cols, config.group_size,
+                                                 _lib.MODE_ID[config.mode.value], None if four else c_out,
+                                                 c_out if four else None, c_scale, c_aux, stream)
+        else:
+            st = L.nncf_amd_float_quantize_batched(n, c_w, _lib.dtype_id(ws[0]), c_rows, c_cols, config.group_size,
+                                                   _lib.MODE_ID[config.mode.value], c_out, c_scale, c_aux, stream)
+    _lib.check(st)
+    res = []
+    for o, s, a in zip(outs, scales, auxs):
+        if asym:
+            res.append(CompressedWeight(o, s, a))
+        else:
+            res.append(CompressedWeight(o, s, None, codebook=a))
+    return res

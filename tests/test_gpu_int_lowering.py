@@ -190,3 +190,40 @@ def test_large_tensor_properties():
     rc, rs, _ = O.compress_weight(w[sl].float().cpu().numpy(), (1,), "int4_sym", 128)
     assert_equal_nan(host(cw.tensor[sl]), rc)
     assert_equal_nan(host(cw.scale[sl]), rs)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("mode,gs", [("int4_sym", 128), ("int4_asym", 64), ("int4_sym", 32), ("int4_sym", -1),
+                                     ("int8_asym", -1), ("nf4", 32), ("mxfp4", 32), ("int4_asym", 8)])
+def test_batched_matches_single_and_oracle(mode, gs, dtype):
+    """multi-tensor launches: ragged tensor sizes (partial tiles, tiny tensors), > 48 tensors (several launches)."""
+    from nncf_amd import weight_lowering as wl
+    rng = np.random.default_rng(3)
+    shapes = [(1, 256), (3, 256), (8, 1024), (64, 512), (5, 768) if gs in (-1, 32, 64, 8) else (5, 1024), (129, 256),
+              (16, 2048), (2, 4096)] * 7  # 56 tensors
+    ws32 = [representable((rng.standard_normal(s) * 0.05).astype(np.float32), dtype) for s in shapes]
+    ws = [to_dev(w, dtype) for w in ws32]
+    cfg = _cfg(mode, gs)
+    got = wl.compress_weights_packed_batched(ws, cfg, want_e8m0=True)
+    assert len(got) == len(ws)
+    for w, w32, cw in zip(ws, ws32, got):
+        single = wl.compress_weight_packed(w, (1,), cfg)
+        assert torch.equal(cw.tensor.reshape(-1), single.tensor.reshape(-1))
+        assert torch.equal(cw.scale.reshape(-1), single.scale.reshape(-1))
+        rc, rs, rz = O.compress_weight(w32, (1,), mode, gs)
+        assert_equal_nan(host(cw.scale).reshape(rs.shape), rs, "scale")
+        if mode.startswith("int"):
+            if mode.startswith("int4"):
+                ref = O.pack_uint4(rc) if mode == "int4_asym" else O.pack_int4(rc)
+            else:
+                ref = rc
+            assert_equal_nan(host(cw.tensor).reshape(ref.shape), ref, "codes")
+            if rz is not None:
+                assert_equal_nan(host(cw.zero_point).reshape(rz.shape), rz, "zp")
+        else:
+            p = host(cw.tensor).ravel()
+            codes = np.stack([p & 15, p >> 4], -1).ravel()
+            lut = O.NF4_QUANTILES if mode == "nf4" else O.E2M1_VALUE_OF_CODE
+            assert np.array_equal(lut[codes], rc.ravel())
+            if mode == "mxfp4":
+                assert np.array_equal(np.ldexp(np.float32(1), host(cw.codebook).astype(np.int32).ravel() - 127), rs.ravel())
