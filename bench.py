@@ -122,20 +122,20 @@ def cpu_baseline(geometry, mode, gs, budget_s=12.0):
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(0)
-    done_bytes, t_total, used = 0, 0.0, []
-    for (o, i) in shapes:
-        w = (torch.randn(o, i, generator=gen) * 0.02).to(torch.bfloat16)
-        t0 = time.perf_counter()
-        compress_int_torch(w, mode, gs, pack=True)
-        dt = time.perf_counter() - t0
-        t_total += dt
-        done_bytes += 2 * w.numel()
-        used.append(f"{o}x{i}")
-        if t_total > budget_s:
-            break
+    ws = [(torch.randn(o, i, generator=gen) * 0.02).to(torch.bfloat16) for (o, i) in shapes]
+    for w in ws[:2]:
+        compress_int_torch(w, mode, gs, pack=True)  # warm-up (thread pool, allocator)
+    done_bytes, t_total, passes = 0, 0.0, 0
+    while t_total < budget_s and passes < 200:
+        for w in ws:
+            t0 = time.perf_counter()
+            compress_int_torch(w, mode, gs, pack=True)
+            t_total += time.perf_counter() - t0
+            done_bytes += 2 * w.numel()
+        passes += 1
     return {"value": round(done_bytes / t_total / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
-            "sample": f"torch-CPU op chain + pack on {len(used)} tensors of one layer ({', '.join(used)}), bf16, "
-                      f"{mode} g{gs}, {t_total:.1f}s"}
+            "sample": f"reference torch-CPU op chain + pack_int4 (oracle/torch_chain.py) on the {len(ws)} tensors of one "
+                      f"{geometry} layer, bf16, {mode} g{gs}, {passes} passes, {t_total:.1f}s of CPU work"}
 
 
 def main():
@@ -208,7 +208,11 @@ def main():
         total_in_bytes = job.in_bytes * world
         value = total_in_bytes / (elapsed / args.steps) / 1e9
         achieved = job.alg_bytes / (dev_ms_per_step * 1e-3) / 1e9
-        kernel = "k_grouped<IntPolicy,bf16,LPG=16,U=4>" if mode.startswith("int4") and gs == 128 else "k_grouped/k_row"
+        batched = not mode.startswith("int8")  # 4-bit modes: multi-tensor launches of <= 48 tensors
+        launches = -(-job.n // 48) if batched else job.n
+        kernel = ("wc::k_grouped_batch<%s, bf16, VPG=%d>" % ("IntPolicy" if job.is_int else "FloatPolicy",
+                                                              (gs if gs != -1 else 0) * 2 // 16)
+                  if batched else "wc::k_row<IntPolicy, bf16>")
         res = {
             "metric": "GB/s bf16 weights compressed (node)",
             "value": round(value, 2),
@@ -228,9 +232,9 @@ def main():
                        "partition": "each rank compresses its own model-sized set of layers; no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": kernel, "launches_per_step": job.n,
-                         "avg_launch_us": round(dev_ms_per_step * 1e3 / job.n, 3),
-                         "algorithmic_bytes_per_launch": round(job.alg_bytes / job.n, 1),
+                         "kernel": kernel, "launches_per_step": launches,
+                         "avg_launch_us": round(dev_ms_per_step * 1e3 / launches, 3),
+                         "algorithmic_bytes_per_launch": round(job.alg_bytes / launches, 1),
                          "device_ms_per_step": round(dev_ms_per_step, 4)},
         }
         if gather_ms is not None:

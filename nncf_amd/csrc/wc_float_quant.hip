@@ -92,7 +92,7 @@ struct FloatPolicy {
     __device__ __forceinline__ void emit(const GroupArgs& a, const Par& p, const float* f, int64_t v) const {
         emit_vec<E>(a, *this, p, f, v);
     }
-    template <int NE, int GPL>
+    template <int NE, int GPL, bool NT>
     __device__ __forceinline__ void emit_lane(const GroupArgs& a, const Par* par, float* f, int64_t e0) const {
         constexpr int SG = NE / GPL;
         int code[NE];
@@ -114,8 +114,8 @@ struct FloatPolicy {
                 for (int i = 0; i < 8; ++i) w[j] |= (uint32_t)code[8 * j + i] << (4 * i);
             }
             uint32_t* dst = (uint32_t*)(a.packed + e0 / 2);
-            if constexpr (NE == 16) *(uint2*)dst = make_uint2(w[0], w[1]);
-            if constexpr (NE == 32) *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+            if constexpr (NE == 16) st<NT>((u32x2*)dst, u32x2{w[0], w[1]});
+            if constexpr (NE == 32) st<NT>((u32x4*)dst, u32x4{w[0], w[1], w[2], w[3]});
         }
         if (a.codes) {
             uint4* dst = (uint4*)((uint8_t*)a.codes + e0);
@@ -168,8 +168,9 @@ struct FloatPolicy {
         return {sc};
     }
     __device__ __forceinline__ Par load(const GroupArgs& a, int64_t g) const { return {a.scale_in[g]}; }
+    template <bool NT>
     __device__ __forceinline__ void store(const GroupArgs& a, int64_t g, const Par& p) const {
-        if (a.scale_out) a.scale_out[g] = p.scale;
+        if (a.scale_out) st<NT>(a.scale_out + g, p.scale);
         if (a.e8m0_out) {
             const uint32_t bits = __builtin_bit_cast(uint32_t, p.scale);
             int e = (int)((bits >> 23) & 0xffu);  // biased exponent == log2(scale) + 127 for normal powers of two

@@ -23,6 +23,15 @@
 
 namespace wc {
 
+// streaming (non-temporal) store for outputs nobody re-reads soon: keeps them out of L2/MALL's way
+template <bool NT, typename T>
+__device__ __forceinline__ void st(T* p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct GroupArgs {
     const void* w;
     const float* scale_in;
@@ -194,9 +203,9 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
         if (live) {
             if ((lane & (LPG - 1)) == 0) {
 #pragma unroll
-                for (int gi = 0; gi < GPL; ++gi) pol.store(o, g0 + gi, par[gi]);
+                for (int gi = 0; gi < GPL; ++gi) pol.template store<false>(o, g0 + gi, par[gi]);
             }
-            pol.template emit_lane<NE, GPL>(o, par, f, v0 * E);
+            pol.template emit_lane<NE, GPL, false>(o, par, f, v0 * E);
         }
     }
 }
@@ -256,14 +265,14 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
 #pragma unroll
             for (int u = 0; u < VPL; ++u)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + src_off[u]),
-                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 2);  // aux 2 = nt: read once
         } else {
             const uint32_t last = (uint32_t)(nvec - base - 1) * 16u;
 #pragma unroll
             for (int u = 0; u < VPL; ++u) {
                 const uint32_t off = src_off[u] < last ? src_off[u] : last;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + off),
-                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 2);  // aux 2 = nt: read once
             }
         }
     };
@@ -308,9 +317,9 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
         if (live) {
             if ((lane & (LPG - 1)) == 0) {
 #pragma unroll
-                for (int gi = 0; gi < GPL; ++gi) pol.store(o, g0 + gi, par[gi]);
+                for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(o, g0 + gi, par[gi]);
             }
-            pol.template emit_lane<NE, GPL>(o, par, f, v0 * E);
+            pol.template emit_lane<NE, GPL, true>(o, par, f, v0 * E);
         }
         i = in;
     }
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(256) void k_row(GroupArgs a, int64_t vpg) {
             par = pol.load(a, live_g ? g : 0);
         }
         if (!live_g) continue;
-        if (t == 0) pol.store(a, g, par);
+        if (t == 0) pol.template store<false>(a, g, par);
 #pragma unroll
         for (int k = 0; k < KEEP; ++k) {
             const int64_t j = t + (int64_t)k * TEAM;
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(256) void k_generic(GroupArgs a) {
     } else {
         par = pol.load(a, g);
     }
-    pol.store(a, g, par);
+    pol.template store<false>(a, g, par);
     int prev_nibble = 0;
     for (int64_t k = 0; k < a.gs; ++k) {
         const int64_t idx = first + k * a.inner;

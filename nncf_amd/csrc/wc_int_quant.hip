@@ -95,9 +95,10 @@ struct IntPolicy {
         finish(p);
         return p;
     }
+    template <bool NT>
     __device__ __forceinline__ void store(const GroupArgs& a, int64_t g, const Par& p) const {
-        if (a.scale_out) a.scale_out[g] = p.scale;
-        if (a.zp_out) a.zp_out[g] = p.zpi;
+        if (a.scale_out) st<NT>(a.scale_out + g, p.scale);
+        if (a.zp_out) st<NT>(a.zp_out + g, p.zpi);
     }
     // scalar form (generic kernel): the reference's operation order verbatim
     __device__ __forceinline__ void quant(float w, const Par& p, int& code, float& value) const {
@@ -156,12 +157,24 @@ struct IntPolicy {
             const float lim = m.bits == 4 ? c4 : 0.5f;
             const bool redo = !p.fast || !(viol <= lim);
             if (redo) {
-                // divergent: exact IEEE path, element by element, only where the tie test failed.  Exact ties are
-                // not rare for bf16/f16 weights (8..11-bit significands make 8*w/max land on x.5 exactly), so the
-                // wave pays one divide per flagged element position, not one per element of the chunk.
+                // divergent, element by element, only where the tie test failed.  Exact ties are NOT rare for
+                // bf16/f16 weights (8..11-bit significands: ~0.25 % of the elements of a N(0, 0.02) bf16 tensor have
+                // w/s exactly on x.5), so they are settled without a divide: with b the half-integer next to t2,
+                // rho = fma(-(b - z), s, w) is zero iff w/s == b - z exactly; then RN(w/s) + z == b exactly and the
+                // reference rounds the tie to even, rintf(b).  Everything else takes the IEEE divide.
 #pragma unroll
                 for (int i = 0; i < C; ++i) {
-                    if (!p.fast || !(fabsf(d[i]) <= lim)) kc[i] = int_quant(f[c0 + i], p.scale, p.zpf, p.has_zp, m);
+                    if (!p.fast) {
+                        kc[i] = int_quant(f[c0 + i], p.scale, p.zpf, p.has_zp, m);
+                    } else if (!(fabsf(d[i]) <= lim)) {
+                        const float w = f[c0 + i];
+                        const float b = floorf(fmaf(w, p.r, z)) + 0.5f;
+                        const float rho = fmaf(-(b - z), p.scale, w);
+                        if (rho == 0.0f)
+                            kc[i] = __builtin_amdgcn_fmed3f(rintf(b), m.level_low, m.level_high);
+                        else
+                            kc[i] = int_quant(w, p.scale, p.zpf, p.has_zp, m);
+                    }
                 }
             }
 #pragma unroll
@@ -183,7 +196,7 @@ struct IntPolicy {
         return m.asym ? w : (w ^ 0x80808080u);
     }
     // N consecutive elements starting at element index e0 (N = 4, 8, 16 or 32; e0 % N == 0)
-    template <int N>
+    template <int N, bool NT = false>
     __device__ __forceinline__ void store_codes(const GroupArgs& a, const float* k, int64_t e0) const {
         if (a.packed) {
             if constexpr (N == 4) {
@@ -194,9 +207,9 @@ struct IntPolicy {
 #pragma unroll
                 for (int j = 0; j < N / 8; ++j) w[j] = nibbles8(k + 8 * j);
                 uint32_t* dst = (uint32_t*)(a.packed + e0 / 2);
-                if constexpr (N == 8) dst[0] = w[0];
-                if constexpr (N == 16) *(uint2*)dst = make_uint2(w[0], w[1]);
-                if constexpr (N == 32) *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+                if constexpr (N == 8) st<NT>(dst, w[0]);
+                if constexpr (N == 16) st<NT>((u32x2*)dst, u32x2{w[0], w[1]});
+                if constexpr (N == 32) st<NT>((u32x4*)dst, u32x4{w[0], w[1], w[2], w[3]});
             }
         }
         if (a.codes) {
@@ -229,12 +242,12 @@ struct IntPolicy {
         store_dq<E>(a, p, k, v * E);
     }
     // grouped kernel: NE consecutive elements of one lane, covering GPL whole groups (or a part of one)
-    template <int NE, int GPL>
+    template <int NE, int GPL, bool NT>
     __device__ __forceinline__ void emit_lane(const GroupArgs& a, const Par* par, float* f, int64_t e0) const {
         constexpr int SG = NE / GPL;
 #pragma unroll
         for (int gi = 0; gi < GPL; ++gi) quant_n<SG>(par[gi], f + gi * SG, f + gi * SG);  // in place
-        store_codes<NE>(a, f, e0);
+        store_codes<NE, NT>(a, f, e0);
 #pragma unroll
         for (int gi = 0; gi < GPL; ++gi) store_dq<SG>(a, par[gi], f + gi * SG, e0 + gi * SG);
     }

@@ -85,6 +85,56 @@ int main(int argc, char** argv) {
     double alg = n * (2.0 + (four ? 0.5 : 1.0) + 4.0 / g * (asym ? 2 : 1));
     printf("kernel mode=%d gs=%lld %lldx%lld: %.2f us  in %.1f GB/s  algorithmic %.1f GB/s (%.1f%% of 8 TB/s)\n", mode,
            (long long)gs, (long long)rows, (long long)cols, us, n * 2.0 / us * 1e-3, alg / us * 1e-3, alg / us * 1e-3 / 80.0);
+    {   // HBM-cold: NB distinct tensors (> 256 MiB Infinity Cache in total) through the batched entry point
+        const int NB = argc > 5 ? atoi(argv[5]) : 16;
+        std::vector<const void*> ws(NB);
+        std::vector<uint8_t*> ps(NB);
+        std::vector<float*> ss(NB);
+        std::vector<int32_t*> zs(NB);
+        std::vector<int64_t> rs(NB, rows), cs(NB, cols);
+        for (int i = 0; i < NB; ++i) {
+            uint16_t* wi;
+            CK(hipMalloc(&wi, n * 2));
+            CK(hipMemcpy(wi, w, n * 2, hipMemcpyDeviceToDevice));
+            ws[i] = wi;
+            CK(hipMalloc(&ps[i], n));
+            CK(hipMalloc(&ss[i], (n / (gs > 0 ? gs : cols)) * 4));
+            CK(hipMalloc(&zs[i], (n / (gs > 0 ? gs : cols)) * 4));
+        }
+        auto runb = [&]() {
+            int rc;
+            if (mode <= NNCF_AMD_INT4_SYM)
+                rc = nncf_amd_int_quantize_batched(NB, ws.data(), NNCF_AMD_BF16, rs.data(), cs.data(), gs, mode,
+                                                   four ? nullptr : (void* const*)ps.data(), four ? ps.data() : nullptr,
+                                                   ss.data(), asym ? zs.data() : nullptr, st);
+            else
+                rc = nncf_amd_float_quantize_batched(NB, ws.data(), NNCF_AMD_BF16, rs.data(), cs.data(), gs, mode, ps.data(),
+                                                     ss.data(), nullptr, st);
+            if (rc) { printf("error %d: %s\n", rc, nncf_amd_last_error()); exit(1); }
+        };
+        for (int i = 0; i < 2; ++i) runb();
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 10; ++i) runb();
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        double usb = ms * 1e3 / 10;
+        printf("batched x%d (HBM-cold): %.2f us  in %.1f GB/s  algorithmic %.1f GB/s (%.1f%% of 8 TB/s)\n", NB, usb,
+               NB * n * 2.0 / usb * 1e-3, NB * alg / usb * 1e-3, NB * alg / usb * 1e-3 / 80.0);
+        // probe over the same distinct buffers
+        int64_t nvecb = n / 8;
+        for (int grid : {2048, 8192}) {
+            CK(hipEventRecord(e0, st));
+            for (int r = 0; r < 5; ++r)
+                for (int i = 0; i < NB; ++i)
+                    hipLaunchKernelGGL(k_probe<4>, dim3(grid), dim3(256), 0, st, (const uint4*)ws[i], (uint32_t*)ps[i], nvecb);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            double u = ms * 1e3 / (5 * NB);
+            printf("probe (HBM-cold) grid=%d: %.2f us per tensor  %.1f GB/s (in+out)\n", grid, u, n * 2.5 / u * 1e-3);
+        }
+    }
     // bandwidth probe: same traffic shape
     int64_t nvec = n / 8;
     for (int grid : {1024, 2048, 4096, 8192, 16384}) {
