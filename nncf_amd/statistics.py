@@ -1,0 +1,172 @@
+"""Host-side mirror of the activation-statistics reducers that feed AWQ, scale estimation and mixed precision
+(src/nncf/common/tensor_statistics/collectors.py:468-540, 924-936; activation_stats.py:20-57;
+statistics.py:260-307; gptq.py:381-396) for torch tensors on an AMD GPU.  One fused HIP pass
+(nncf_amd_reduce_activation_stats) computes every statistic of one activation."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from functools import reduce
+from operator import mul
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from nncf_amd import _lib
+from nncf_amd.errors import UnsupportedModelError
+
+
+def activation_stats(x: torch.Tensor, want_mean: bool = True, want_stats: bool = True):
+    """x viewed as [batch, tokens, hidden] (leading axes folded into batch).
+    Returns (mean fp32 [hidden] over batch and tokens | None,
+             stats fp32 [4] = mean(var_tokens), max(var_tokens), mean(absmax_tokens), sum(x*x) | None)."""
+    _lib.require_gpu(x, "activation_stats")
+    if x.dtype == torch.float64:
+        x = x.float()
+    if x.ndim < 2:
+        x = x.reshape(1, 1, -1) if x.ndim == 1 else x.reshape(1, 1, 1)
+    x = x.contiguous()
+    hidden, tokens = x.shape[-1], x.shape[-2]
+    batch = math.prod(x.shape[:-2])
+    dev = x.device
+    mean = torch.empty(hidden, dtype=torch.float32, device=dev) if want_mean else None
+    stats = torch.empty(4, dtype=torch.float32, device=dev) if want_stats else None
+    L = _lib.lib()
+    need = L.nncf_amd_reduce_workspace(batch, tokens, hidden)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        st = L.nncf_amd_reduce_activation_stats(_lib.ptr(x), _lib.dtype_id(x), batch, tokens, hidden, _lib.ptr(mean),
+                                                _lib.ptr(stats), _lib.ptr(ws), need, _lib.stream_of(x))
+    _lib.check(st)
+    return mean, stats
+
+
+def _norm_axes(ndim: int, axes) -> Tuple[int, ...]:
+    if axes is None:
+        return tuple(range(ndim))
+    return tuple(sorted(a % ndim for a in axes))
+
+
+class _ReducerBase:
+    """collectors.py:83-157 (out-of-place path only)."""
+
+    def __init__(self, axes=None, inplace: bool = False):
+        self._axes = axes
+        self._keepdims = True
+        self.inplace = inplace
+
+    def __call__(self, x: List[torch.Tensor]):
+        if any(t.numel() == 0 for t in x):
+            return None
+        return self._reduce_out_of_place(x)
+
+    def __eq__(self, o):
+        return isinstance(o, self.__class__) and self._axes == o._axes
+
+    def __hash__(self):
+        return hash((self.__class__.__name__, self._axes))
+
+
+class RawReducer(_ReducerBase):
+    def _reduce_out_of_place(self, x):
+        return x
+
+
+class ShapeReducer(_ReducerBase):
+    def _reduce_out_of_place(self, x):
+        return [torch.tensor(tuple(x[0].shape), dtype=torch.int32, device=x[0].device)]
+
+
+class MeanReducer(_ReducerBase):
+    """collectors.py:512-516 for axes == all-but-the-last (the weight-compression statistic, algorithm.py:1357-1370)."""
+
+    def _reduce_out_of_place(self, x):
+        t = x[0]
+        axes = _norm_axes(t.ndim, self._axes)
+        if axes != tuple(range(t.ndim - 1)):
+            msg = f"nncf_amd MeanReducer reduces all axes but the last; got axes={self._axes} for ndim={t.ndim}"
+            raise UnsupportedModelError(msg)
+        mean, _ = activation_stats(t.reshape(1, -1, t.shape[-1]), want_stats=False)
+        shape = [1] * (t.ndim - 1) + [t.shape[-1]]
+        # torch.mean accumulates bf16/f16 in fp32 and rounds once to the input dtype
+        return [mean.to(t.dtype if t.dtype.is_floating_point else torch.float32).reshape(shape)]
+
+
+class _TokenStatReducer(_ReducerBase):
+    _index = 0
+
+    def _reduce_out_of_place(self, x):
+        t = x[0]
+        axes = _norm_axes(t.ndim, self._axes)
+        if t.ndim < 2 or axes != (t.ndim - 2,):
+            msg = f"nncf_amd {type(self).__name__} reduces axis -2; got axes={self._axes} for ndim={t.ndim}"
+            raise UnsupportedModelError(msg)
+        _, stats = activation_stats(t, want_mean=False)
+        return [stats[self._index].to(t.dtype)]
+
+
+class MeanVarianceReducer(_TokenStatReducer):
+    """collectors.py:519-524."""
+    _index = 0
+
+
+class MaxVarianceReducer(_TokenStatReducer):
+    """collectors.py:527-532."""
+    _index = 1
+
+
+class MeanAbsMaxReducer(_TokenStatReducer):
+    """collectors.py:535-540."""
+    _index = 2
+
+
+class HAWQAggregator:
+    """collectors.py:924-936 (the running division is reference behaviour)."""
+
+    def __init__(self, num_samples: Optional[int] = None):
+        self._num_samples = num_samples
+        self._collected = 0
+        self._container = 0.0
+
+    def register_reduced_input(self, x: torch.Tensor) -> None:
+        if self._num_samples is not None and self._collected >= self._num_samples:
+            return
+        _, stats = activation_stats(x, want_mean=False)
+        self._container = (self._container + stats[3]) / x.numel()
+        self._collected += 1
+
+    def aggregate(self):
+        return self._container * 2 / self._collected
+
+
+@dataclass
+class WCTensorStatistic:
+    """statistics.py:260-307."""
+    mean_values: List[torch.Tensor] = field(default_factory=list)
+    shape_values: List[Tuple[int, ...]] = field(default_factory=list)
+
+
+def activations_to_wc_statistics(activations: Sequence[torch.Tensor]) -> WCTensorStatistic:
+    """gptq.py:381-396."""
+    means, shapes = [], []
+    for act in activations:
+        shapes.append(tuple(act.shape))
+        m, _ = activation_stats(act.reshape(1, -1, act.shape[-1]), want_stats=False)
+        means.append(m.to(act.dtype))
+    return WCTensorStatistic(means, shapes)
+
+
+def process_stats(stats: WCTensorStatistic, subset_size: int, act_ch_axis: int = -1):
+    """activation_stats.py:20-57 (tiny; torch on device)."""
+    X = torch.stack(list(stats.mean_values))
+    axes = list(range(1, X.ndim)) + [0]
+    X_full = X.permute(axes)
+    if X_full.shape[-1] > subset_size and subset_size > 0:
+        lens = [reduce(mul, tuple(s[:act_ch_axis]) + tuple(s[act_ch_axis % len(s) + 1:]), 1) for s in stats.shape_values]
+        step = X_full.shape[-1] // subset_size
+        idxs = [i[0] for i in sorted(enumerate(lens), key=lambda v: -v[1])][::step]
+        X = X_full[..., idxs]
+    else:
+        X = X_full
+    s = X_full.abs().amax(dim=-1)
+    return s, X

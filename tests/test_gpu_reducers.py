@@ -1,0 +1,81 @@
+"""GPU parity: fused activation-statistics kernel vs the oracle and the golden fixtures.
+Reductions reorder, so floats are compared at 2e-6 relative for fp32 (the reference's own alignment test uses
+rtol 1e-4 for reductions, test_compression_functions.py:284-324) and at 1 ulp of the dtype for bf16/f16 results."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wc_oracle as O
+from tests.gpu_utils import host, to_dev
+
+pytestmark = pytest.mark.gpu
+RT = {"f32": 3e-6, "bf16": 2 ** -7, "f16": 2 ** -10}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_golden_reducers(golden, dtype):
+    from nncf_amd import statistics as S
+    g = golden("reducers")
+    x = to_dev(g["x_f32"], dtype)
+    rt = RT[dtype]
+    m = S.MeanReducer(axes=(0, 1))._reduce_out_of_place([x])[0]
+    assert tuple(m.shape) == (1, 1, x.shape[-1]) and m.dtype == x.dtype
+    np.testing.assert_allclose(host(m), g[f"mean_{dtype}"], rtol=rt, atol=2e-6 if dtype == "f32" else 1e-3)
+    np.testing.assert_allclose(host(S.MeanVarianceReducer(axes=(1,))._reduce_out_of_place([x])[0]),
+                               g[f"meanvar_{dtype}"], rtol=rt)
+    np.testing.assert_allclose(host(S.MaxVarianceReducer(axes=(-2,))._reduce_out_of_place([x])[0]),
+                               g[f"maxvar_{dtype}"], rtol=rt)
+    np.testing.assert_allclose(host(S.MeanAbsMaxReducer(axes=(1,))._reduce_out_of_place([x])[0]),
+                               g[f"meanabsmax_{dtype}"], rtol=rt)
+
+
+def test_golden_hawq_and_process_stats(golden):
+    from nncf_amd import statistics as S
+    g = golden("reducers")
+    agg = S.HAWQAggregator(num_samples=4)
+    for i in range(4):
+        agg.register_reduced_input(to_dev(g[f"hawq_x{i}"], "f32"))
+    np.testing.assert_allclose(float(agg.aggregate()), float(g["hawq_result"]), rtol=1e-5)
+    means = [torch.from_numpy(m).cuda() for m in g["ps_means"]]
+    shapes = [tuple(int(v) for v in s) for s in g["ps_shapes"]]
+    for subset in (4, 3, 32):
+        s, X = S.process_stats(S.WCTensorStatistic(means, shapes), subset, -1)
+        assert np.array_equal(host(s), g[f"ps_s_{subset}"]) and np.array_equal(host(X), g[f"ps_X_{subset}"])
+
+
+def test_reference_literals():
+    # tests/cross_fw/test_templates/template_test_weights_compression.py:52-58
+    from nncf_amd import statistics as S
+    x = torch.tensor([[[-4.0, 1, 2], [0, 0, 0], [0, 0, 0]]], device="cuda")
+    assert np.isclose(float(S.MaxVarianceReducer((-2,))._reduce_out_of_place([x])[0]), 3.555555, atol=1e-5)
+    assert np.isclose(float(S.MeanVarianceReducer((-2,))._reduce_out_of_place([x])[0]), 1.555555, atol=1e-5)
+    assert np.isclose(float(S.MeanAbsMaxReducer((-2,))._reduce_out_of_place([x])[0]), 2.333333, atol=1e-5)
+    agg = S.HAWQAggregator()
+    agg.register_reduced_input(x)
+    assert np.isclose(float(agg.aggregate()), (16 + 1 + 4) * 2 / 9)
+    # tests/common/test_reducers_and_aggregators.py:713-726
+    agg = S.HAWQAggregator()
+    for i in range(1, 5):
+        agg.register_reduced_input(torch.arange(8 * i, dtype=torch.float32, device="cuda").reshape(1, 8, i))
+    assert np.isclose(float(agg.aggregate()), 165.61627, rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 2048, 4096), (3, 77, 100), (2, 1, 8), (1, 5000, 24), (4, 33, 1030)])
+def test_oracle_shapes(shape, dtype):
+    """every split/vector path; one channel has a large mean (outlier) to exercise the shifted variance."""
+    from nncf_amd import statistics as S
+    rng = np.random.default_rng(1)
+    x32 = rng.standard_normal(shape).astype(np.float32)
+    x32[..., 3] = x32[..., 3] * 0.01 + 300.0
+    x = to_dev(x32, dtype)
+    xr = host(x).astype(np.float32)
+    mean, stats = S.activation_stats(x)
+    rt = 3e-6 if dtype == "f32" else 2 ** -7
+    np.testing.assert_allclose(host(mean), np.mean(xr.astype(np.float64), axis=(0, 1)), rtol=3e-6, atol=5e-6)  # sums of ~1e4 O(1) terms in fp32
+    np.testing.assert_allclose(float(stats[0]), O.mean_variance_reducer(xr, (1,), dtype), rtol=max(rt, 1e-4))
+    np.testing.assert_allclose(float(stats[1]), O.max_variance_reducer(xr, (1,), dtype), rtol=max(rt, 1e-4))
+    np.testing.assert_allclose(float(stats[2]), O.mean_abs_max_reducer(xr, (1,)), rtol=3e-6)
+    np.testing.assert_allclose(float(stats[3]), np.sum(xr.astype(np.float64) ** 2), rtol=1e-5)
+    with pytest.raises(Exception):
+        S.MeanReducer(axes=(0,))._reduce_out_of_place([x])
