@@ -189,11 +189,13 @@ int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype, int64_t to
  * appends scales/zps at group index (i1+i)/group_size.
  *   weight, quantized: [rows, k] fp32;  hinv: [k, k] fp32 upper Cholesky factor of H^-1;
  *   scales: fp32 [rows, k/group_size]; zps: int32 same shape (asymmetric integer modes) or NULL.
+ *   use_given_params != 0: the entries of scales/zps for the groups starting in this block were filled in by
+ *   the caller (scale estimation inside GPTQ, gptq.py:319-327) and are used instead of being computed.
  * The trailing update W[:, i2:] -= Err @ Hinv[i1:i2, i2:] (gptq.py:363) is a plain GEMM left to the caller.
  */
 int nncf_amd_gptq_block(const float* weight, float* quantized, float* err_block, const float* hinv, int64_t rows,
                         int64_t k, int64_t i1, int64_t count, int64_t group_size, int mode, float* scales,
-                        int32_t* zps, void* stream);
+                        int32_t* zps, int use_given_params, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,252 +6,9 @@
 // is read once, every output byte written once.  Kernel skeletons: wc_group_kernels.h.
 #include <vector>
 
-#include "wc_group_kernels.h"
+#include "wc_int_policy.h"
 
 namespace wc {
-
-// Fast exact rounding.  The reference needs k = rne(RN(w/s) [+ z]) with an IEEE fp32 divide per element
-// (~10 VALU ops, one of them a quarter-rate v_rcp).  Per group we take r = RN(1/s) once and per element
-//     t = RN(w*r),  t2 = RN(t + z),  k = rne(t2).
-// With x = RN(w/s), x2 = RN(x + z):  |t - x| <= 3.01*2^-24*|t|  and  |t2 - x2| <= 3.01*2^-24*(|t| + |t2|)
-// (one rounding each in r, w*r and w/s, plus the two sums' roundings), so k can differ from the reference
-// only if a half-integer lies within that distance of t2.  Such elements (|t2 - k| > 0.5 - 2^-21*(|t|+|t2|),
-// probability ~2^-18 per int4 element), NaN/inf intermediates and groups whose scale is outside
-// [2^-100, 2^100] are recomputed with the IEEE divide, so the result is bit-exact by construction.
-constexpr float kTieMargin = 4.76837158203125e-07f;  // 2^-21
-
-struct IntPolicy {
-    IntMode m;
-    float pack_bias;  // 8 * 0x1111 for signed nibbles, 0 for unsigned
-    struct Stat {
-        float lo, hi;
-    };
-    struct Par {
-        float scale, zpf, r;
-        int zpi;
-        bool has_zp, fast;
-    };
-    static __device__ __forceinline__ void init_shared(float*) {}
-    __device__ __forceinline__ IntPolicy(const GroupArgs& a, const float*) : m(int_mode(a.mode)) {
-        pack_bias = m.asym ? 0.0f : 34952.0f;
-    }
-    __device__ __forceinline__ Stat stat_init() const { return {__builtin_inff(), -__builtin_inff()}; }
-    __device__ __forceinline__ void stat_add(Stat& s, float f) const {
-        s.lo = fminf(s.lo, f);
-        s.hi = fmaxf(s.hi, f);
-    }
-    template <int E>
-    __device__ __forceinline__ void stat_add_vec(Stat& s, const float* f) const {
-#pragma unroll
-        for (int i = 0; i < E; i += 2) {
-            s.lo = min3_raw(s.lo, f[i], f[i + 1]);
-            s.hi = max3_raw(s.hi, f[i], f[i + 1]);
-        }
-    }
-    template <int L>
-    __device__ __forceinline__ void stat_lanes(Stat& s) const {
-        minmax_dpp16<(L < 16 ? L : 16)>(s.lo, s.hi);
-        if constexpr (L >= 32) {
-            s.lo = fminf(s.lo, __shfl_xor(s.lo, 16, 64));
-            s.hi = fmaxf(s.hi, __shfl_xor(s.hi, 16, 64));
-        }
-        if constexpr (L >= 64) {
-            s.lo = fminf(s.lo, __shfl_xor(s.lo, 32, 64));
-            s.hi = fmaxf(s.hi, __shfl_xor(s.hi, 32, 64));
-        }
-    }
-    __device__ __forceinline__ void stat_block(Stat& s, float* smem) const {
-        s.lo = block_allreduce<4>(s.lo, OpMin(), smem);
-        s.hi = block_allreduce<4>(s.hi, OpMax(), smem + 8);
-    }
-    __device__ __forceinline__ void finish(Par& p) const {
-        p.r = 1.0f / p.scale;
-        const float as = fabsf(p.scale);
-        p.fast = (as >= 7.888609052210118e-31f) && (as <= 1.2676506002282294e+30f);  // [2^-100, 2^100]
-        if (m.bits == 4 && !(fabsf(p.zpf) <= 15.0f)) p.fast = false;  // the 4-bit constant margins assume |z| <= 15
-    }
-    __device__ __forceinline__ Par compute(const Stat& s) const {
-        Par p;
-        int_params(s.lo, s.hi, m, p.scale, p.zpf, p.zpi);
-        p.has_zp = m.asym;
-        finish(p);
-        return p;
-    }
-    __device__ __forceinline__ Par load(const GroupArgs& a, int64_t g) const {
-        Par p;
-        p.scale = a.scale_in[g];
-        p.has_zp = a.zp_in != nullptr;
-        p.zpi = 0;
-        p.zpf = 0.0f;
-        if (p.has_zp) {
-            if (a.zp_dtype == NNCF_AMD_ZP_I32) {
-                p.zpi = ((const int32_t*)a.zp_in)[g];
-                p.zpf = (float)p.zpi;
-            } else {
-                p.zpf = ((const float*)a.zp_in)[g];  // weight_lowering.py:679-680: added as float
-                p.zpi = (int)p.zpf;
-            }
-        }
-        finish(p);
-        return p;
-    }
-    template <bool NT>
-    __device__ __forceinline__ void store(const GroupArgs& a, int64_t g, const Par& p) const {
-        if (a.scale_out) st<NT>(a.scale_out + g, p.scale);
-        if (a.zp_out) st<NT>(a.zp_out + g, p.zpi);
-    }
-    // scalar form (generic kernel): the reference's operation order verbatim
-    __device__ __forceinline__ void quant(float w, const Par& p, int& code, float& value) const {
-        value = int_quant(w, p.scale, p.zpf, p.has_zp, m);
-        code = (int)value;
-    }
-    // weight_lowering.py:442-443: (int32(q) - zp).astype(f32) * scale; q, zp small integers -> exact subtraction
-    __device__ __forceinline__ float dq(int, float value, const Par& p) const {
-        return p.has_zp ? (value - p.zpf) * p.scale : value * p.scale;
-    }
-    __device__ __forceinline__ int nibble(int code) const { return code + (m.asym ? 0 : 8); }
-
-    // k[i] <- clip(rne(w/s [+ z])) for N elements sharing one parameter set; exact (see kTieMargin above).
-    // f and k may alias: elements are processed in chunks of C whose inputs stay intact until the chunk's
-    // rare exact re-computation has been decided.  The fast path's t2 = fma(w, r, z) (one rounding) is
-    // covered by the same error bound as RN(RN(w*r) + z).  The tie test keeps a running maximum of the
-    // violation instead of a per-element flag: one v_max3 per two elements.
-    template <int N>
-    __device__ __forceinline__ void quant_n(const Par& p, const float* f, float* k) const {
-        constexpr int C = N < 8 ? N : 8;
-        const float z = p.has_zp ? p.zpf : 0.0f;
-        // 4-bit: |t2| <= 16 and |t| <= 31 wherever the clip does not decide anyway -> constant margins
-        //   sym : 3.01*2^-24*16 < 2^-18        asym: 3.01*2^-24*(31+16) < 2^-16
-        const float c4 = p.has_zp ? 0.5f - 1.52587890625e-05f : 0.5f - 3.814697265625e-06f;
-#pragma unroll
-        for (int c0 = 0; c0 < N; c0 += C) {
-            float kc[C], d[C];
-            if (m.bits == 4) {
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    const float t2 = fmaf(f[c0 + i], p.r, z);
-                    const float kk = rintf(t2);
-                    d[i] = t2 - kk;
-                    kc[i] = __builtin_amdgcn_fmed3f(kk, m.level_low, m.level_high);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    const float t = f[c0 + i] * p.r;
-                    const float t2 = t + z;
-                    const float kk = rintf(t2);
-                    // violation measure: |t2-kk| + (|t|+|t2|)*margin must stay <= 0.5
-                    d[i] = fmaf(fabsf(t) + fabsf(t2), kTieMargin, fabsf(t2 - kk));
-                    kc[i] = __builtin_amdgcn_fmed3f(kk, m.level_low, m.level_high);
-                }
-            }
-            float viol = 0.0f;
-            if constexpr (C >= 2) {
-#pragma unroll
-                for (int i = 0; i < C; i += 2) viol = max3_abs_raw(viol, d[i], d[i + 1]);
-            } else {
-                viol = fabsf(d[0]);
-            }
-            // +-inf weights give d = NaN, which v_max3 drops: fine, the fast path's clip(+-inf) already equals the
-            // reference's result.  NaN weights are outside the contract (the reference's cast of NaN is undefined).
-            const float lim = m.bits == 4 ? c4 : 0.5f;
-            const bool redo = !p.fast || !(viol <= lim);
-            if (redo) {
-                // divergent, element by element, only where the tie test failed.  Exact ties are NOT rare for
-                // bf16/f16 weights (8..11-bit significands: ~0.25 % of the elements of a N(0, 0.02) bf16 tensor have
-                // w/s exactly on x.5), so they are settled without a divide: with b the half-integer next to t2,
-                // rho = fma(-(b - z), s, w) is zero iff w/s == b - z exactly; then RN(w/s) + z == b exactly and the
-                // reference rounds the tie to even, rintf(b).  Everything else takes the IEEE divide.
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    if (!p.fast) {
-                        kc[i] = int_quant(f[c0 + i], p.scale, p.zpf, p.has_zp, m);
-                    } else if (!(fabsf(d[i]) <= lim)) {
-                        const float w = f[c0 + i];
-                        const float b = floorf(fmaf(w, p.r, z)) + 0.5f;
-                        const float rho = fmaf(-(b - z), p.scale, w);
-                        if (rho == 0.0f)
-                            kc[i] = __builtin_amdgcn_fmed3f(rintf(b), m.level_low, m.level_high);
-                        else
-                            kc[i] = int_quant(w, p.scale, p.zpf, p.has_zp, m);
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < C; ++i) k[c0 + i] = kc[i];
-        }
-    }
-    // 8 clipped codes -> one dword of nibbles, assembled in the float domain (exact integers < 2^16 per half)
-    __device__ __forceinline__ uint32_t nibbles8(const float* k) const {
-        const float p01 = fmaf(k[1], 16.0f, k[0]), p23 = fmaf(k[3], 16.0f, k[2]);
-        const float p45 = fmaf(k[5], 16.0f, k[4]), p67 = fmaf(k[7], 16.0f, k[6]);
-        const float lo = fmaf(p23, 256.0f, p01) + pack_bias, hi = fmaf(p67, 256.0f, p45) + pack_bias;
-        return (uint32_t)lo | ((uint32_t)hi << 16);
-    }
-    __device__ __forceinline__ uint32_t bytes4(const float* k) const {
-        const float off = m.asym ? 0.0f : 128.0f;
-        uint32_t w = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) w = __builtin_amdgcn_cvt_pk_u8_f32(k[b] + off, b, w);
-        return m.asym ? w : (w ^ 0x80808080u);
-    }
-    // N consecutive elements starting at element index e0 (N = 4, 8, 16 or 32; e0 % N == 0)
-    template <int N, bool NT = false>
-    __device__ __forceinline__ void store_codes(const GroupArgs& a, const float* k, int64_t e0) const {
-        if (a.packed) {
-            if constexpr (N == 4) {
-                const float p01 = fmaf(k[1], 16.0f, k[0]), p23 = fmaf(k[3], 16.0f, k[2]);
-                *(uint16_t*)(a.packed + e0 / 2) = (uint16_t)(uint32_t)(fmaf(p23, 256.0f, p01) + pack_bias);
-            } else {
-                uint32_t w[N / 8];
-#pragma unroll
-                for (int j = 0; j < N / 8; ++j) w[j] = nibbles8(k + 8 * j);
-                uint32_t* dst = (uint32_t*)(a.packed + e0 / 2);
-                if constexpr (N == 8) st<NT>(dst, w[0]);
-                if constexpr (N == 16) st<NT>((u32x2*)dst, u32x2{w[0], w[1]});
-                if constexpr (N == 32) st<NT>((u32x4*)dst, u32x4{w[0], w[1], w[2], w[3]});
-            }
-        }
-        if (a.codes) {
-            uint32_t* dst = (uint32_t*)((uint8_t*)a.codes + e0);
-            if constexpr (N == 4) dst[0] = bytes4(k);
-            if constexpr (N == 8) *(uint2*)dst = make_uint2(bytes4(k), bytes4(k + 4));
-            if constexpr (N >= 16) {
-#pragma unroll
-                for (int j = 0; j < N / 16; ++j)
-                    ((uint4*)dst)[j] = make_uint4(bytes4(k + 16 * j), bytes4(k + 16 * j + 4), bytes4(k + 16 * j + 8),
-                                                  bytes4(k + 16 * j + 12));
-            }
-        }
-    }
-    template <int N>
-    __device__ __forceinline__ void store_dq(const GroupArgs& a, const Par& p, const float* k, int64_t e0) const {
-        if (a.dq) {
-            float4* o = (float4*)(a.dq + e0);
-#pragma unroll
-            for (int j = 0; j < N / 4; ++j)
-                o[j] = make_float4(dq(0, k[4 * j], p), dq(0, k[4 * j + 1], p), dq(0, k[4 * j + 2], p), dq(0, k[4 * j + 3], p));
-        }
-    }
-    // row kernel: one vector of E elements
-    template <int E>
-    __device__ __forceinline__ void emit(const GroupArgs& a, const Par& p, const float* f, int64_t v) const {
-        float k[E];
-        quant_n<E>(p, f, k);
-        store_codes<E>(a, k, v * E);
-        store_dq<E>(a, p, k, v * E);
-    }
-    // grouped kernel: NE consecutive elements of one lane, covering GPL whole groups (or a part of one)
-    template <int NE, int GPL, bool NT>
-    __device__ __forceinline__ void emit_lane(const GroupArgs& a, const Par* par, float* f, int64_t e0) const {
-        constexpr int SG = NE / GPL;
-#pragma unroll
-        for (int gi = 0; gi < GPL; ++gi) quant_n<SG>(par[gi], f + gi * SG, f + gi * SG);  // in place
-        store_codes<NE, NT>(a, f, e0);
-#pragma unroll
-        for (int gi = 0; gi < GPL; ++gi) store_dq<SG>(a, par[gi], f + gi * SG, e0 + gi * SG);
-    }
-};
 
 static int int_quantize_impl(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
                              int64_t group_size, int mode, const float* scale_in, const void* zp_in, int zp_dtype,

@@ -1,0 +1,158 @@
+"""GPU parity of the data-aware rows: scale estimation, AWQ, GPTQ Hessian and GPTQ column sweep vs the golden
+fixtures (reference outputs) and the oracle.  Tolerances: scales / adjusted weights <= 1e-5 relative where the
+arithmetic is order-stable; GPTQ after the Cholesky trio is compared like the reference's own test does
+(np.isclose on most entries, tests/openvino/native/quantization/test_gptq.py:421-452) because it is chaotic
+under last-bit differences of LAPACK."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wc_oracle as O
+from tests.gpu_utils import host, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(mode, gs):
+    from nncf_amd.parameters import WeightCompressionConfig
+    return WeightCompressionConfig(mode=mode, group_size=gs)
+
+
+def _stats(g):
+    from nncf_amd.statistics import WCTensorStatistic
+    means = [torch.from_numpy(m).cuda() for m in g["means"]]
+    shapes = [tuple(int(v) for v in s) for s in g["shapes"]]
+    return WCTensorStatistic(means, shapes)
+
+
+@pytest.mark.parametrize("gs", [32, -1])
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym", "nf4"])
+def test_golden_scale_estimation(golden, mode, gs):
+    from nncf_amd import scale_estimation as SE
+    g = golden("se_awq")
+    s, z = SE.calculate_quantization_params(_stats(g), to_dev(g["w"], "f32"), (1,), _cfg(mode, gs), -1, 8, 3, 4)
+    ref = g[f"se_{mode}_g{gs}_scale"]
+    assert tuple(s.shape) == ref.shape
+    np.testing.assert_allclose(host(s), ref, rtol=1e-5, atol=1e-9)
+    if z is not None:
+        assert np.array_equal(host(z), g[f"se_{mode}_g{gs}_zp"])
+
+
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym"])
+def test_golden_awq(golden, mode):
+    from nncf_amd import awq
+    g = golden("se_awq")
+    w = to_dev(g["w"], "f32")
+    sc = awq.data_aware_step(w, (1,), _cfg(mode, 32), _stats(g), -1, 8, 0.02, 0.0, 1.0, 20)
+    np.testing.assert_allclose(host(sc), g[f"awq_{mode}_scale"], rtol=1e-5)
+    np.testing.assert_allclose(host(awq.data_free_step(w, 0)), g["awq_data_free_scale"], rtol=1e-6)
+
+
+def test_golden_hessian(golden):
+    from nncf_amd import gptq
+    g = golden("gptq")
+    xs = [torch.from_numpy(x).cuda() for x in g["xs"]]
+    H = gptq.calculate_hessian(xs)
+    assert tuple(H.shape) == g["H_torch"].shape
+    np.testing.assert_allclose(host(H), g["H_torch"], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(host(H)[0], host(H)[0].T)  # written symmetric by construction
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("T,K", [(300, 256), (37, 100), (1000, 384), (64, 4096)])
+def test_hessian_vs_float64(T, K, dtype):
+    from nncf_amd import gptq
+    rng = np.random.default_rng(T + K)
+    xs32 = [rng.standard_normal((1, T, K)).astype(np.float32) for _ in range(3)]
+    xs = [to_dev(x, dtype) for x in xs32]
+    xr = [host(x).astype(np.float64) for x in xs]
+    H = host(gptq.calculate_hessian(xs))[0]
+    ref = sum(x[0].T @ x[0] for x in xr) * (2.0 / 3.0)
+    np.testing.assert_allclose(H, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    # moe / 3-D weight form keeps the expert axis (gptq.py:216-223)
+    x3 = [to_dev(rng.standard_normal((2, 16, 64)).astype(np.float32), "f32") for _ in range(2)]
+    H3 = host(gptq.calculate_hessian(x3, is_3d_weight=True))
+    ref3 = O.gptq_hessian([host(x) for x in x3], is_3d_weight=True)
+    np.testing.assert_allclose(H3, ref3, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("se", [0, 1])
+@pytest.mark.parametrize("gs", [16, 64, -1])
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym", "nf4"])
+def test_golden_gptq_quantize(golden, mode, gs, se):
+    if se and mode == "nf4":
+        pytest.skip("reference runs scale estimation inside GPTQ for integer modes only")
+    from nncf_amd import gptq
+    g = golden("gptq")
+    H = torch.from_numpy(g["H_torch"][0].copy()).cuda()
+    W = torch.from_numpy(g["w"].copy()).cuda()
+    xs = [torch.from_numpy(x).cuda() for x in g["xs"]]
+    q, s, z = gptq.quantize_weights(H, W, _cfg(mode, gs), xs, 0.1, 32, bool(se))
+    key = f"torch_{mode}_g{gs}_se{se}"
+    assert tuple(s.shape) == g[key + "_scale"].shape
+    close = np.isclose(host(q), g[key + "_q"], rtol=1e-4, atol=1e-6)
+    assert close.mean() > 0.97, close.mean()
+    sclose = np.isclose(host(s), g[key + "_scale"], rtol=1e-3, atol=1e-6)
+    assert sclose.mean() > 0.97, sclose.mean()
+    if z is not None:
+        assert (host(z) == g[key + "_zp"]).mean() > 0.97
+
+
+@pytest.mark.parametrize("mode,gs", [("int4_sym", 128), ("int4_asym", 64), ("nf4", 32), ("mxfp4", 32), ("int4_sym", -1)])
+def test_gptq_sweep_matches_oracle_given_same_hinv(mode, gs):
+    """The HIP column sweep against the oracle's Python loop with the SAME inverse-Hessian factor (computed once, in
+    float64 on the host), so that the only difference left is the sweep itself: codes must match exactly."""
+    from nncf_amd import _lib
+    rng = np.random.default_rng(5)
+    N, K, bs = 48, 256, 128
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    X = rng.standard_normal((512, K))
+    Hd = 2.0 / 512 * X.T @ X
+    Hd[np.diag_indices(K)] += 0.1 * np.mean(np.diag(Hd))
+    hinv = np.linalg.cholesky(np.linalg.inv(Hd)).T.astype(np.float32).copy()
+    # oracle sweep
+    Wo, Q_ref = W.copy(), np.zeros_like(W)
+    g = gs if gs != -1 else K
+    scales_ref = []
+    for i1 in range(0, K, bs):
+        i2 = min(i1 + bs, K)
+        Wb, Eb = Wo[:, i1:i2].copy(), np.zeros((N, i2 - i1), np.float32)
+        for i in range(i2 - i1):
+            c = i1 + i
+            if c % g == 0:
+                wg = Wo[:, c:c + g]
+                if O.is_integer(mode):
+                    sc, zp = O.calculate_integer_quantization_params(wg, (1,), mode)
+                else:
+                    sc, zp = O.calculate_float_quantization_params(wg, (1,), mode), None
+                scales_ref.append(sc)
+            col = Wb[:, i][:, None]
+            qc = (O.integer_quantize_dequantize_weight(col, mode, -1, None, sc, zp) if O.is_integer(mode)
+                  else O.float_quantize_dequantize_weight(col, mode, -1, None, sc)).reshape(-1)
+            Q_ref[:, c] = qc
+            err = (Wb[:, i] - qc) / hinv[c, c]
+            Wb[:, i:] -= err[:, None] * hinv[c, c:i2][None, :]
+            Eb[:, i] = err
+        Wo[:, i2:] -= Eb @ hinv[i1:i2, i2:]
+    # HIP sweep through the C ABI, trailing GEMM in float32 numpy-equivalent (torch.matmul) -> compare per block
+    Wd = torch.from_numpy(W.copy()).cuda()
+    hd = torch.from_numpy(hinv).cuda()
+    Qd = torch.zeros_like(Wd)
+    ng = K // g
+    sc_d = torch.empty((N, ng), dtype=torch.float32, device="cuda")
+    zp_d = torch.empty((N, ng), dtype=torch.int32, device="cuda")
+    L = _lib.lib()
+    for i1 in range(0, K, bs):
+        i2 = min(i1 + bs, K)
+        err = torch.empty((N, i2 - i1), dtype=torch.float32, device="cuda")
+        st = L.nncf_amd_gptq_block(_lib.ptr(Wd), _lib.ptr(Qd), _lib.ptr(err), _lib.ptr(hd), N, K, i1, i2 - i1, g,
+                                   _lib.MODE_ID[mode], _lib.ptr(sc_d), _lib.ptr(zp_d), 0, _lib.stream_of(Wd))
+        _lib.check(st)
+        if i2 < K:
+            Wd[:, i2:] -= err @ hd[i1:i2, i2:]
+    ref_scales = np.concatenate(scales_ref, axis=1)
+    np.testing.assert_allclose(host(sc_d), ref_scales, rtol=2e-5)
+    close = np.isclose(host(Qd), Q_ref, rtol=1e-4, atol=1e-7)
+    assert close.mean() > 0.995, close.mean()
+    # first block: no GEMM involved yet -> bit exact
+    assert np.array_equal(host(Qd)[:, :bs], Q_ref[:, :bs])
