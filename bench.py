@@ -213,6 +213,14 @@ def main():
         kernel = ("wc::k_grouped_batch<%s, bf16, VPG=%d>" % ("IntPolicy" if job.is_int else "FloatPolicy",
                                                               (gs if gs != -1 else 0) * 2 // 16)
                   if batched else "wc::k_row<IntPolicy, bf16>")
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json), same command
+            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
+                traffic = json.load(fh).get(args.workload, {}).get("traffic_bytes_per_launch")
+            if traffic is not None and (args.layers or world != 1):
+                traffic = None
+        except OSError:
+            pass
         res = {
             "metric": "GB/s bf16 weights compressed (node)",
             "value": round(value, 2),
@@ -231,7 +239,7 @@ def main():
                        "tensors_per_step": job.n, "elements_per_step_per_gpu": job.elems,
                        "partition": "each rank compresses its own model-sized set of layers; no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kernel, "launches_per_step": launches,
                          "avg_launch_us": round(dev_ms_per_step * 1e3 / launches, 3),
                          "algorithmic_bytes_per_launch": round(job.alg_bytes / launches, 1),
