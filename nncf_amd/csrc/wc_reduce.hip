@@ -12,8 +12,8 @@
 namespace wc {
 
 static inline int reduce_nsplit(int64_t batch, int64_t tokens, int64_t hidden) {
-    const int64_t col_blocks = (hidden + 1023) / 1024;
-    int64_t want = 2048 / (batch * col_blocks > 0 ? batch * col_blocks : 1);
+    const int64_t col_blocks = (hidden + 511) / 512;  // one wave covers 512 bf16 / 256 fp32 channels
+    int64_t want = 8192 / (batch * col_blocks > 0 ? batch * col_blocks : 1);
     const int64_t max_split = (tokens + 31) / 32;
     if (want > max_split) want = max_split;
     if (want > 256) want = 256;
@@ -23,10 +23,10 @@ static inline int reduce_nsplit(int64_t batch, int64_t tokens, int64_t hidden) {
 
 // partial layout: ws[((b * nsplit + s) * 3 + q) * hidden + k], q = 0: sum d, 1: sum d^2, 2: max |x|
 template <int DT, bool VEC>
-__global__ __launch_bounds__(256) void k_act_partials(const void* __restrict__ x, int64_t tokens, int64_t hidden, int nsplit,
+__global__ __launch_bounds__(64) void k_act_partials(const void* __restrict__ x, int64_t tokens, int64_t hidden, int nsplit,
                                                       float* __restrict__ ws) {
     constexpr int E = VEC ? Elem<DT>::kPerVec : 1;
-    const int64_t col0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * E;
+    const int64_t col0 = ((int64_t)blockIdx.x * 64 + threadIdx.x) * E;
     if (col0 >= hidden) return;
     const int s = blockIdx.y;
     const int64_t b = blockIdx.z;
@@ -98,67 +98,112 @@ __device__ __forceinline__ float round_like(int dt, float v) {
     return v;
 }
 
-// single block: merges the token splits, emits mean[hidden] and the four scalars
+// stage 1 of the merge: thread (k, b) folds the token splits of one (batch, channel) -> column sum for the mean,
+// and the block folds its variance / abs-max / square sums into one partial record (4 doubles).
+// merge workspace layout (after the partials): colsum[batch][hidden] floats, then records[blocks][4] doubles.
 template <int DT>
-__global__ __launch_bounds__(1024) void k_act_finalize(const void* __restrict__ x, int64_t batch, int64_t tokens,
-                                                       int64_t hidden, int nsplit, const float* __restrict__ ws,
-                                                       float* mean_out, float* stats_out) {
-    __shared__ double red[4][16];
-    double sum_var = 0.0, sum_amax = 0.0, sum_sq = 0.0;
-    float max_var = -__builtin_inff();
+__global__ __launch_bounds__(256) void k_act_merge(const void* __restrict__ x, int64_t tokens, int64_t hidden, int nsplit,
+                                                   const float* __restrict__ ws, float* __restrict__ colsum,
+                                                   double* __restrict__ records) {
+    __shared__ double red[4][4];
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t b = blockIdx.y;
     const float T = (float)tokens;
-    for (int64_t k = threadIdx.x; k < hidden; k += 1024) {
-        double col_sum = 0.0;
-        for (int64_t b = 0; b < batch; ++b) {
-            float sd = 0.0f, sq = 0.0f, am = 0.0f;
-            for (int s = 0; s < nsplit; ++s) {
-                const float* p = ws + ((b * nsplit + s) * 3) * hidden + k;
-                sd += p[0];
-                sq += p[hidden];
-                am = fmaxf(am, p[2 * hidden]);
-            }
-            const float x0 = Elem<DT>::load(x, b * tokens * hidden + k);
-            float var = (sq - sd * sd / T) / T;
-            var = var < 0.0f ? 0.0f : var;
-            var = round_like(DT, var);  // torch.var returns the input dtype before the outer mean / max
-            sum_var += var;
-            max_var = fmaxf(max_var, var);
-            sum_amax += am;
-            sum_sq += (double)sq + 2.0 * (double)x0 * (double)sd + (double)T * (double)x0 * (double)x0;
-            col_sum += (double)sd + (double)T * (double)x0;
+    double s_var = 0.0, s_amax = 0.0, s_sq = 0.0;
+    float m_var = -__builtin_inff();
+    if (k < hidden) {
+        float sd = 0.0f, sq = 0.0f, am = 0.0f;
+        for (int s = 0; s < nsplit; ++s) {
+            const float* p = ws + ((b * nsplit + s) * 3) * hidden + k;
+            sd += p[0];
+            sq += p[hidden];
+            am = fmaxf(am, p[2 * hidden]);
         }
-        if (mean_out) mean_out[k] = (float)(col_sum / ((double)batch * (double)tokens));
+        const float x0 = Elem<DT>::load(x, b * tokens * hidden + k);
+        float var = (sq - sd * sd / T) / T;
+        var = var < 0.0f ? 0.0f : var;
+        var = round_like(DT, var);  // torch.var returns the input dtype before the outer mean / max
+        s_var = var;
+        m_var = var;
+        s_amax = am;
+        s_sq = (double)sq + 2.0 * (double)x0 * (double)sd + (double)T * (double)x0 * (double)x0;
+        colsum[b * hidden + k] = sd + T * x0;
     }
-    // block reduction of the scalars
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int off = 32; off > 0; off >>= 1) {
-        sum_var += __shfl_xor(sum_var, off, 64);
-        sum_amax += __shfl_xor(sum_amax, off, 64);
-        sum_sq += __shfl_xor(sum_sq, off, 64);
-        max_var = fmaxf(max_var, __shfl_xor(max_var, off, 64));
+        s_var += __shfl_xor(s_var, off, 64);
+        s_amax += __shfl_xor(s_amax, off, 64);
+        s_sq += __shfl_xor(s_sq, off, 64);
+        m_var = fmaxf(m_var, __shfl_xor(m_var, off, 64));
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
-        red[0][wave] = sum_var;
-        red[1][wave] = sum_amax;
-        red[2][wave] = sum_sq;
-        red[3][wave] = (double)max_var;
+        red[0][wave] = s_var;
+        red[1][wave] = s_amax;
+        red[2][wave] = s_sq;
+        red[3][wave] = (double)m_var;
     }
     __syncthreads();
-    if (threadIdx.x == 0 && stats_out) {
-        double a = 0, c = 0, d = 0, mx = red[3][0];
-        for (int w = 0; w < 16; ++w) {
-            a += red[0][w];
-            c += red[1][w];
-            d += red[2][w];
-            mx = red[3][w] > mx ? red[3][w] : mx;
-        }
-        const double n = (double)batch * (double)hidden;
-        stats_out[0] = (float)(a / n);
-        stats_out[1] = (float)mx;
-        stats_out[2] = (float)(c / n);
-        stats_out[3] = (float)d;
+    if (threadIdx.x == 0) {
+        double* r = records + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        r[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        r[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        r[2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        double mx = red[3][0];
+        for (int w = 1; w < 4; ++w) mx = red[3][w] > mx ? red[3][w] : mx;
+        r[3] = mx;
     }
 }
+
+// stage 2: mean[k] = sum_b colsum[b][k] / (B*T) over a grid of blocks; block 0 also folds the records
+__global__ __launch_bounds__(256) void k_act_finalize(int64_t batch, int64_t tokens, int64_t hidden,
+                                                      const float* __restrict__ colsum, const double* __restrict__ records,
+                                                      int64_t n_records, float* mean_out, float* stats_out) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (mean_out && k < hidden) {
+        double acc = 0.0;
+        for (int64_t b = 0; b < batch; ++b) acc += (double)colsum[b * hidden + k];
+        mean_out[k] = (float)(acc / ((double)batch * (double)tokens));
+    }
+    if (blockIdx.x == 0 && stats_out) {
+        __shared__ double red[4][4];
+        double a = 0.0, c = 0.0, d = 0.0, mx = -1.0;
+        for (int64_t r = threadIdx.x; r < n_records; r += 256) {
+            a += records[r * 4];
+            c += records[r * 4 + 1];
+            d += records[r * 4 + 2];
+            mx = records[r * 4 + 3] > mx ? records[r * 4 + 3] : mx;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, 64);
+            c += __shfl_xor(c, off, 64);
+            d += __shfl_xor(d, off, 64);
+            const double o = __shfl_xor(mx, off, 64);
+            mx = o > mx ? o : mx;
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+            red[0][wave] = a;
+            red[1][wave] = c;
+            red[2][wave] = d;
+            red[3][wave] = mx;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double n = (double)batch * (double)hidden;
+            double m = red[3][0];
+            for (int w = 1; w < 4; ++w) m = red[3][w] > m ? red[3][w] : m;
+            stats_out[0] = (float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n);
+            stats_out[1] = (float)m;
+            stats_out[2] = (float)((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / n);
+            stats_out[3] = (float)(red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+        }
+    }
+}
+
+static inline size_t partial_floats(int64_t batch, int64_t tokens, int64_t hidden) {
+    return (size_t)batch * (size_t)reduce_nsplit(batch, tokens, hidden) * 3u * (size_t)hidden;
+}
+static inline size_t align8(size_t n) { return (n + 7) / 8 * 8; }
 
 template <int DT>
 static int run_reduce(const void* x, int64_t batch, int64_t tokens, int64_t hidden, float* mean_out, float* stats_out,
@@ -166,17 +211,24 @@ static int run_reduce(const void* x, int64_t batch, int64_t tokens, int64_t hidd
     const int nsplit = reduce_nsplit(batch, tokens, hidden);
     const bool vec = (((uintptr_t)x & 15u) == 0) && (hidden % Elem<DT>::kPerVec == 0);
     if (vec) {
-        const int64_t cols_per_block = 256 * Elem<DT>::kPerVec;
+        const int64_t cols_per_block = 64 * Elem<DT>::kPerVec;
         dim3 grid((unsigned)((hidden + cols_per_block - 1) / cols_per_block), (unsigned)nsplit, (unsigned)batch);
-        hipLaunchKernelGGL((k_act_partials<DT, true>), grid, dim3(256), 0, s, x, tokens, hidden, nsplit, ws);
+        hipLaunchKernelGGL((k_act_partials<DT, true>), grid, dim3(64), 0, s, x, tokens, hidden, nsplit, ws);
     } else {
-        dim3 grid((unsigned)((hidden + 255) / 256), (unsigned)nsplit, (unsigned)batch);
-        hipLaunchKernelGGL((k_act_partials<DT, false>), grid, dim3(256), 0, s, x, tokens, hidden, nsplit, ws);
+        dim3 grid((unsigned)((hidden + 63) / 64), (unsigned)nsplit, (unsigned)batch);
+        hipLaunchKernelGGL((k_act_partials<DT, false>), grid, dim3(64), 0, s, x, tokens, hidden, nsplit, ws);
     }
     int st = launch_status("act_partials");
     if (st != NNCF_AMD_OK) return st;
-    hipLaunchKernelGGL((k_act_finalize<DT>), dim3(1), dim3(1024), 0, s, x, batch, tokens, hidden, nsplit, (const float*)ws,
-                       mean_out, stats_out);
+    float* colsum = ws + align8(partial_floats(batch, tokens, hidden));
+    double* records = (double*)(colsum + align8((size_t)batch * (size_t)hidden));
+    const unsigned kb = (unsigned)((hidden + 255) / 256);
+    hipLaunchKernelGGL((k_act_merge<DT>), dim3(kb, (unsigned)batch), dim3(256), 0, s, x, tokens, hidden, nsplit,
+                       (const float*)ws, colsum, records);
+    st = launch_status("act_merge");
+    if (st != NNCF_AMD_OK) return st;
+    hipLaunchKernelGGL(k_act_finalize, dim3(kb), dim3(256), 0, s, batch, tokens, hidden, (const float*)colsum,
+                       (const double*)records, (int64_t)kb * batch, mean_out, stats_out);
     return launch_status("act_finalize");
 }
 
@@ -184,7 +236,9 @@ static int run_reduce(const void* x, int64_t batch, int64_t tokens, int64_t hidd
 
 extern "C" size_t nncf_amd_reduce_workspace(int64_t batch, int64_t tokens, int64_t hidden) {
     if (batch <= 0 || tokens <= 0 || hidden <= 0) return 0;
-    return (size_t)batch * (size_t)wc::reduce_nsplit(batch, tokens, hidden) * 3u * (size_t)hidden * sizeof(float);
+    const size_t kb = (size_t)((hidden + 255) / 256);
+    return (wc::align8(wc::partial_floats(batch, tokens, hidden)) + wc::align8((size_t)batch * (size_t)hidden)) * sizeof(float) +
+           kb * (size_t)batch * 4 * sizeof(double);
 }
 
 extern "C" int nncf_amd_reduce_activation_stats(const void* x, int x_dtype, int64_t batch, int64_t tokens,
