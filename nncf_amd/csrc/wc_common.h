@@ -170,6 +170,7 @@ struct IntMode {
     int bits;
     int asym;
     float level_low, level_high;
+    float inv_half;  // 1 / 2^(bits-1), exact
 };
 __host__ __device__ inline IntMode int_mode(int mode) {
     IntMode m;
@@ -177,6 +178,7 @@ __host__ __device__ inline IntMode int_mode(int mode) {
     m.asym = (mode == NNCF_AMD_INT8_ASYM || mode == NNCF_AMD_INT4_ASYM) ? 1 : 0;
     m.level_low = m.asym ? 0.0f : -(float)(1 << (m.bits - 1));
     m.level_high = m.asym ? (float)((1 << m.bits) - 1) : (float)((1 << (m.bits - 1)) - 1);
+    m.inv_half = m.bits == 8 ? 0.0078125f : 0.125f;
     return m;
 }
 
@@ -198,7 +200,7 @@ __device__ __forceinline__ void int_params(float lo, float hi, const IntMode& m,
     } else {
         float a = fabsf(lo);
         float s = (a >= hi) ? a : -hi;
-        s = s / (float)(1 << (m.bits - 1));
+        s = s * m.inv_half;  // == s / 2^(bits-1) bit for bit: both are the correctly rounded value of the same real
         if (fabsf(s) < kEps) s = kEps;
         scale = s;
         zpi = 0;

@@ -85,6 +85,23 @@ struct FloatPolicy {
     __device__ __forceinline__ void emit(const GroupArgs& a, const Par& p, const float* f, int64_t v) const {
         emit_vec<E>(a, *this, p, f, v);
     }
+    // multi-tensor kernel: NE consecutive elements of one lane -> NE/8 dwords of nibble codes
+    template <int NE, int GPL>
+    __device__ __forceinline__ void pack_lane(const Par* par, float* f, uint32_t* out) const {
+        constexpr int SG = NE / GPL;
+#pragma unroll
+        for (int j = 0; j < NE / 8; ++j) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int code;
+                float val;
+                quant(f[8 * j + q], par[(8 * j + q) / SG], code, val);
+                w |= (uint32_t)code << (4 * q);
+            }
+            out[j] = w;
+        }
+    }
     template <int NE, int GPL, bool NT>
     __device__ __forceinline__ void emit_lane(const GroupArgs& a, const Par* par, float* f, int64_t e0) const {
         constexpr int SG = NE / GPL;

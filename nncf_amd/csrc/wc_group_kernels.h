@@ -19,6 +19,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "wc_common.h"
 
 namespace wc {
@@ -217,17 +219,82 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
 // batch (tile_start = prefix sums) and the resident waves stride over them, prefetching their next tile by LDS-DMA
 // while they work on the current one.  Always "lean": packed codes + computed parameters only.
 constexpr int kMaxBatch = 48;
+#ifndef WC_GROUPS
+#define WC_GROUPS 32
+#endif
+constexpr int kClaimGroupsUsed = WC_GROUPS;
+constexpr int kClaimSlots = 32, kClaimGroups = 128, kClaimStride = 32, kClaimDevices = 16;
+constexpr int kBatchGrid = 2048;  // 256 CUs x 8 blocks; the resident waves stride over the rest
 struct BatchArgs {
     int n;
     int mode;
-    int64_t tile_start[kMaxBatch + 1];
-    int64_t nvec[kMaxBatch];
+    uint32_t tile_start[kMaxBatch + 1];  // 32-bit tile ids: every per-tile decision is wave-uniform SALU work
+    uint32_t nfull[kMaxBatch];           // whole tiles of the tensor
+    uint32_t rem[kMaxBatch];             // vectors in its trailing partial tile (0: none)
     const void* w[kMaxBatch];
     uint8_t* packed[kMaxBatch];
     float* scale[kMaxBatch];
     void* aux[kMaxBatch];  // int32 zero points (asymmetric integer modes) or uint8 E8M0 scales (MXFP4); may be NULL
+    uint32_t* ctr;                  // claim counters of this launch's slot (kClaimStride words apart)
+    uint32_t log2_groups;           // claim groups of this launch = 1 << log2_groups (<= grid)
+    uint32_t base[kClaimGroups];    // value of each counter when the launch starts
+    uint32_t part_lo[kClaimGroups + 1];  // tile range of each part (proportional to the blocks serving it)
 };
+// Tile claim counters.  Waves make unequal progress (the hardware favours the oldest waves: with a static stride
+// the first blocks finish in half the time of the last ones and the launch ends in a long under-occupied tail), so
+// tiles are claimed: the tile range is cut into 2^k contiguous parts, block x serves part (x / 8) mod 2^k (eight
+// consecutive blocks sit on the eight XCDs: every part is served by all XCDs and by old and young blocks alike),
+// and a wave takes the next tile of its part with one returning atomic add (several counters, because one
+// address sustains only ~10^8 atomics/s).  Counters are never reset: every wave stops at its first failed claim, so a launch adds
+// exactly tiles + waves to a counter and the host keeps the running values (g_claim_host).  Launches take slots
+// round-robin; more than kClaimSlots multi-tensor launches in flight at once (on different streams) would share
+// a slot: not supported.
+static __device__ uint32_t g_claim[kClaimSlots][kClaimGroups][kClaimStride];
+static uint32_t g_claim_host[kClaimDevices][kClaimSlots][kClaimGroups];
+static unsigned g_next_slot[kClaimDevices];
+static std::mutex g_claim_mutex;
+constexpr int64_t kMaxBatchVec = (int64_t)1 << 30;  // vectors per tensor and per launch (32-bit tile / group indices)
 
+// appends tensor j (nvec 16-byte vectors) to a batch; returns the running tile count
+static inline uint32_t batch_set(BatchArgs& b, int j, uint32_t acc, int64_t nvec, const void* w, uint8_t* packed,
+                                 float* scale, void* aux) {
+    constexpr int64_t TILE = 64 * kVPL;
+    b.tile_start[j] = acc;
+    b.nfull[j] = (uint32_t)(nvec / TILE);
+    b.rem[j] = (uint32_t)(nvec % TILE);
+    b.w[j] = w;
+    b.packed[j] = packed;
+    b.scale[j] = scale;
+    b.aux[j] = aux;
+    acc += (uint32_t)((nvec + TILE - 1) / TILE);
+    b.tile_start[j + 1] = acc;
+    return acc;
+}
+
+// one 16-byte-per-lane LDS-DMA load, non-temporal: global (SGPR base + 32-bit VGPR offset) -> LDS (M0 + lane*16).
+// Written out so that the issue path holds no VALU instruction at all (a VALU op there queues behind the other
+// waves' arithmetic and delays the load by up to a whole compute phase).
+// returning atomic add of 1 on a wave-uniform address, issued by the calling lanes; the caller waits (vmcnt).
+// Inline so that the compiler neither aggregates it across the wave nor waits for the result on the spot.
+__device__ __forceinline__ uint32_t claim_async(uint32_t* ctr) {
+    uint32_t old;
+    const uint32_t zero = 0, one = 1;
+    asm volatile("global_atomic_add %0, %1, %2, %3 sc0 sc1" : "=v"(old) : "v"(zero), "v"(one), "s"(ctr) : "memory");  // sc0: return, sc1: agent scope
+    return old;
+}
+__device__ __forceinline__ void dma16_nt(const char* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory", "m0");
+}
+
+// Per-wave schedule (one tile = 64*VPL vectors in flight per wave, processed from registers):
+//     wait DMA(t) -> LDS image to registers -> issue DMA(t + stride) -> store packed codes of the PREVIOUS tile
+//     -> statistics, parameters, parameter store -> quantize + pack (kept in registers until the next round)
+// The deferred store keeps the s_waitcnt vmcnt(0) at the top from waiting on a store that was issued a moment
+// ago (vmcnt counts stores too); the tensor descriptors of the current and the next tile stay in SGPRs and are
+// reloaded from the kernel arguments only when a wave crosses into another tensor.
 template <typename Policy, int DT, int VPG>
 __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     constexpr int VPL = kVPL;
@@ -237,6 +304,7 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     constexpr int LPG = VPG >= VPL ? VPG / VPL : 1;
     constexpr int SG = NE / GPL;
     constexpr int TILE = 64 * VPL;
+    constexpr int NW = NE / 8;  // packed dwords per lane
     __shared__ Vec16 stage[4][TILE];
     __shared__ float lds[kPolicyLds];
     Policy::init_shared(lds);
@@ -247,9 +315,8 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Vec16* my = stage[wave];
-    const int64_t total = b.tile_start[b.n];
-    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t wave_count = (int64_t)gridDim.x * 4;
+    const uint32_t total = b.tile_start[b.n];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)my;
     uint32_t src_off[VPL];
 #pragma unroll
     for (int u = 0; u < VPL; ++u) {
@@ -257,33 +324,65 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
         src_off[u] = (uint32_t)((sidx & ~3) + ((sidx & 3) ^ ((sidx >> 4) & 3))) * 16u;
     }
     const int rot = (lane >> 2) & 3;
-    auto issue_dma = [&](int64_t t, int i) {
-        const int64_t base = (t - b.tile_start[i]) * TILE;
-        const int64_t nvec = b.nvec[i];
-        const char* tbase = (const char*)b.w[i] + base * 16;  // wave-uniform
-        if (base + TILE <= nvec) {
+    struct Desc {  // wave-uniform
+        uint32_t start, end, nfull, rem;
+        const char* w;
+        uint8_t* packed;
+        float* scale;
+        void* aux;
+    };
+    auto load_desc = [&](int i) {
+        Desc d;
+        d.start = b.tile_start[i];
+        d.end = b.tile_start[i + 1];
+        d.nfull = b.nfull[i];
+        d.rem = b.rem[i];
+        d.w = (const char*)b.w[i];
+        d.packed = b.packed[i];
+        d.scale = b.scale[i];
+        d.aux = b.aux[i];
+        return d;
+    };
+    auto issue_dma = [&](uint32_t t, const Desc& d) {
+        const uint32_t lt = t - d.start;  // tile inside the tensor
+        const char* tbase = d.w + (uint64_t)lt * (TILE * 16);
+        if (lt < d.nfull) {
 #pragma unroll
-            for (int u = 0; u < VPL; ++u)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + src_off[u]),
-                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 2);  // aux 2 = nt: read once
+            for (int u = 0; u < VPL; ++u) dma16_nt(tbase, src_off[u], lds_base + u * 1024);
         } else {
-            const uint32_t last = (uint32_t)(nvec - base - 1) * 16u;
+            const uint32_t last = (d.rem - 1) * 16u;  // partial tile: clamp to the last valid vector
 #pragma unroll
-            for (int u = 0; u < VPL; ++u) {
-                const uint32_t off = src_off[u] < last ? src_off[u] : last;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + off),
-                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 2);  // aux 2 = nt: read once
-            }
+            for (int u = 0; u < VPL; ++u) dma16_nt(tbase, src_off[u] < last ? src_off[u] : last, lds_base + u * 1024);
         }
     };
-    int64_t t = wave_global;
+    auto store_packed = [&](uint8_t* dst, const uint32_t* w) {
+        if constexpr (NW == 1) st<true>((uint32_t*)dst, w[0]);
+        if constexpr (NW == 2) st<true>((u32x2*)dst, u32x2{w[0], w[1]});
+        if constexpr (NW == 4) st<true>((u32x4*)dst, u32x4{w[0], w[1], w[2], w[3]});
+    };
+    // this block's part of the tile range and its claim counter
+    const uint32_t part = (blockIdx.x >> 3) & ((1u << b.log2_groups) - 1);
+    const uint32_t lo = b.part_lo[part], hi = b.part_lo[part + 1];
+    uint32_t* ctr = b.ctr + part * kClaimStride;
+    const uint32_t cbase = lo - b.base[part];  // tile = cbase + claimed value (mod 2^32)
+    uint32_t claim = 0;
+    if (lane == 0) claim = claim_async(ctr);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
+    uint32_t t = cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+    if (t >= hi) return;  // (a wave makes exactly one failing claim: the host's running counter values rely on it)
+#ifdef WC_CLK
+    const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int i = 0;
-    if (t < total) {
-        while (t >= b.tile_start[i + 1]) ++i;
-        issue_dma(t, i);
-    }
-    for (; t < total; t += wave_count) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    while (t >= b.tile_start[i + 1]) ++i;
+    Desc cur = load_desc(i);
+    issue_dma(t, cur);
+    // claim of the tile after this one: in flight together with the DMA, both waited for at the loop top
+    if (lane == 0) claim = claim_async(ctr);
+    uint32_t pend[NW];
+    uint8_t* pend_dst = nullptr;  // per lane; NULL = nothing pending
+    for (;;) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
         float f[NE];
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
@@ -291,21 +390,32 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
             unpack<DT>(raw, f + k * E);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int64_t tn = t + wave_count;
-        int in = i;
-        if (tn < total) {
-            while (tn >= b.tile_start[in + 1]) ++in;
-            issue_dma(tn, in);
+        const uint32_t tn = cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+        Desc nxt = cur;
+        if (tn < hi) {
+            if (tn >= nxt.end) {
+                do ++i; while (tn >= b.tile_start[i + 1]);
+                nxt = load_desc(i);
+            }
+            issue_dma(tn, nxt);
+            if (lane == 0) claim = claim_async(ctr);
         }
-        const int64_t base = (t - b.tile_start[i]) * TILE;
-        const int64_t nvec = b.nvec[i];
-        o.packed = b.packed[i];
-        o.scale_out = b.scale[i];
-        o.zp_out = (int32_t*)b.aux[i];
-        o.e8m0_out = (uint8_t*)b.aux[i];
-        const int64_t v0 = base + (int64_t)lane * VPL;
-        const bool live = v0 < nvec;
-        const int64_t g0 = v0 / VPG;
+        if (pend_dst) store_packed(pend_dst, pend);
+        const uint32_t lt = t - cur.start;
+        o.scale_out = cur.scale;
+        o.zp_out = (int32_t*)cur.aux;
+        o.e8m0_out = (uint8_t*)cur.aux;
+        const uint32_t in_tile = lt < cur.nfull ? (uint32_t)TILE : cur.rem;
+        const bool live = (uint32_t)(lane * VPL) < in_tile;  // rem % VPL == 0 (host): a lane is all live or all dead
+        const uint32_t v0 = lt * TILE + lane * VPL;          // first vector of this lane, < 2^30
+        const uint32_t g0 = v0 / VPG;
+#if defined(WC_EXP) && WC_EXP == 1
+#pragma unroll
+        for (int q = 0; q < NW; ++q) pend[q] = 0;
+#pragma unroll
+        for (int q = 0; q < NE; ++q) pend[q % NW] ^= __float_as_uint(f[q]);
+        (void)g0;
+#else
         typename Policy::Par par[GPL];
 #pragma unroll
         for (int gi = 0; gi < GPL; ++gi) {
@@ -314,28 +424,92 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
             if constexpr (LPG > 1) pol.template stat_lanes<LPG>(st);
             par[gi] = pol.compute(st);
         }
-        if (live) {
-            if ((lane & (LPG - 1)) == 0) {
+        if (live && (lane & (LPG - 1)) == 0) {
 #pragma unroll
-                for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(o, g0 + gi, par[gi]);
-            }
-            pol.template emit_lane<NE, GPL, true>(o, par, f, v0 * E);
+            for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(o, g0 + gi, par[gi]);
         }
-        i = in;
+        pol.template pack_lane<NE, GPL>(par, f, pend);
+#endif
+        pend_dst = live ? cur.packed + (uint64_t)v0 * (E / 2) : nullptr;
+        if (tn >= hi) break;
+        t = tn;
+        cur = nxt;
     }
+    if (pend_dst) store_packed(pend_dst, pend);
+#ifdef WC_CLK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) {
+        uint64_t* rec = (uint64_t*)b.scale[0] + (size_t)(blockIdx.x * 4 + wave) * 4;
+        rec[0] = rt0;
+        rec[1] = __builtin_amdgcn_s_memrealtime();
+        rec[2] = __builtin_readcyclecounter() - clk0;
+        rec[3] = 0;
+    }
+#endif
+}
+
+// grid of a multi-tensor launch: one resident set of blocks (never a second, under-occupied round), at most one
+// wave per tile.
+template <typename Policy, int DT, int VPG>
+static int batch_grid(int64_t tiles) {
+    static int resident = 0;  // blocks the device holds at once
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_grouped_batch<Policy, DT, VPG>, 256, 0) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
+            resident = kBatchGrid;
+        else
+            resident = per_cu * prop.multiProcessorCount;
+    }
+    const int64_t blocks = (tiles + 3) / 4;
+    return (int)(blocks < resident ? blocks : resident);
 }
 
 template <typename Policy, int DT, int VPG>
-static void launch_batch(const BatchArgs& b, hipStream_t s) {
-    const int64_t tiles = b.tile_start[b.n];
-    int64_t blocks = (tiles + 3) / 4;
-    static const int64_t cap = getenv("NNCF_AMD_GRID_CAP") ? atoll(getenv("NNCF_AMD_GRID_CAP")) : 2048;
-    if (blocks > cap) blocks = cap;
+static hipError_t launch_batch_kernel(BatchArgs& b, hipStream_t s) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kClaimDevices) return hipErrorInvalidDevice;
+    uint32_t* sym = nullptr;
+    e = hipGetSymbolAddress((void**)&sym, HIP_SYMBOL(g_claim));
+    if (e != hipSuccess) return e;
+    const uint32_t tiles = b.tile_start[b.n];
+    const int blocks = batch_grid<Policy, DT, VPG>(tiles);
+    if (blocks < 1) return hipSuccess;
+    int lg = 0;
+    while ((16 << lg) <= blocks && (2 << lg) <= kClaimGroupsUsed) ++lg;  // at least one octet of blocks per part
+    const int groups = 1 << lg;
+    uint32_t blocks_on[kClaimGroups] = {};
+    for (int x = 0; x < blocks; ++x) ++blocks_on[(x >> 3) & (groups - 1)];
+    std::lock_guard<std::mutex> lock(g_claim_mutex);
+    const unsigned slot = g_next_slot[dev]++ % kClaimSlots;
+    uint32_t* shadow = g_claim_host[dev][slot];
+    b.ctr = sym + (size_t)slot * kClaimGroups * kClaimStride;
+    b.log2_groups = (uint32_t)lg;
+    uint32_t seen = 0;
+    for (int g = 0; g < groups; ++g) {
+        b.base[g] = shadow[g];
+        b.part_lo[g] = (uint32_t)((uint64_t)tiles * seen / (uint32_t)blocks);
+        seen += blocks_on[g];
+    }
+    b.part_lo[groups] = tiles;
     hipLaunchKernelGGL((k_grouped_batch<Policy, DT, VPG>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+    e = hipPeekAtLastError();
+    if (e != hipSuccess) return e;
+    // the launch adds tiles-in-part + waves-on-part to each counter (every wave stops at its first failed claim)
+    for (int g = 0; g < groups; ++g) shadow[g] += (b.part_lo[g + 1] - b.part_lo[g]) + 4u * blocks_on[g];
+    return hipSuccess;
+}
+
+template <typename Policy, int DT, int VPG>
+static void launch_batch(BatchArgs& b, hipStream_t s) {
+    (void)launch_batch_kernel<Policy, DT, VPG>(b, s);  // errors surface through launch_status()
 }
 
 template <typename Policy, int DT>
-static bool dispatch_batch(int vpg, const BatchArgs& b, hipStream_t s) {
+static bool dispatch_batch(int vpg, BatchArgs& b, hipStream_t s) {
     switch (vpg) {
         case 1: launch_batch<Policy, DT, 1>(b, s); return true;
         case 2: launch_batch<Policy, DT, 2>(b, s); return true;
@@ -376,7 +550,7 @@ static bool batch_fits(int w_dtype, const BatchItem* items, int n, int64_t group
         if (vpg != -1 && vpg != (int)v) return false;
         vpg = (int)v;
         const int64_t nvec = items[i].rows * items[i].cols * eb / 16;
-        if (nvec % kVPL != 0) return false;
+        if (nvec % kVPL != 0 || nvec > kMaxBatchVec) return false;
         if (!is16(items[i].w) || !items[i].packed || !is16(items[i].packed) || !items[i].scale) return false;
     }
     *vpg_out = vpg;
@@ -386,23 +560,21 @@ static bool batch_fits(int w_dtype, const BatchItem* items, int n, int64_t group
 template <typename Policy>
 static int run_batch(int w_dtype, const BatchItem* items, int n, int vpg, int mode, const char* what, hipStream_t s) {
     const int eb = w_dtype == NNCF_AMD_F32 ? 4 : 2;
-    for (int first = 0; first < n; first += kMaxBatch) {
+    for (int first = 0; first < n;) {
         BatchArgs b = {};
-        b.n = n - first < kMaxBatch ? n - first : kMaxBatch;
         b.mode = mode;
-        int64_t acc = 0;
-        for (int j = 0; j < b.n; ++j) {
+        uint32_t acc = 0;
+        int64_t vecs = 0;
+        int j = 0;
+        for (; j < kMaxBatch && first + j < n; ++j) {
             const BatchItem& it = items[first + j];
             const int64_t nvec = it.rows * it.cols * eb / 16;
-            b.tile_start[j] = acc;
-            acc += (nvec + 64 * kVPL - 1) / (64 * kVPL);
-            b.nvec[j] = nvec;
-            b.w[j] = it.w;
-            b.packed[j] = it.packed;
-            b.scale[j] = it.scale;
-            b.aux[j] = it.aux;
+            if (j > 0 && vecs + nvec > kMaxBatchVec) break;  // keep the launch's tile count in 32 bits
+            vecs += nvec;
+            acc = batch_set(b, j, acc, nvec, it.w, it.packed, it.scale, it.aux);
         }
-        b.tile_start[b.n] = acc;
+        b.n = j;
+        first += j;
         bool ok;
         switch (w_dtype) {
             case NNCF_AMD_F32: ok = dispatch_batch<Policy, NNCF_AMD_F32>(vpg, b, s); break;
@@ -556,21 +728,14 @@ static void launch_grouped(const GroupArgs& a, hipStream_t s) {
     const int64_t tiles = (nvec + 64 * kVPL - 1) / (64 * kVPL);
     // 256 CUs x 8 resident blocks; more tiles than that are strided over by the resident waves
     int64_t blocks = (tiles + 3) / 4;
-    static const int64_t cap = getenv("NNCF_AMD_GRID_CAP") ? atoll(getenv("NNCF_AMD_GRID_CAP")) : 2048;
-    if (blocks > cap) blocks = cap;
-    const bool lean = a.packed && a.scale_out && !a.scale_in && !a.codes && !a.values && !a.dq;
+    if (blocks > kBatchGrid) blocks = kBatchGrid;
+    const bool lean = a.packed && a.scale_out && !a.scale_in && !a.codes && !a.values && !a.dq && nvec <= kMaxBatchVec;
     if (lean) {
         BatchArgs b = {};
         b.n = 1;
         b.mode = a.mode;
-        b.tile_start[0] = 0;
-        b.tile_start[1] = tiles;
-        b.nvec[0] = nvec;
-        b.w[0] = a.w;
-        b.packed[0] = a.packed;
-        b.scale[0] = a.scale_out;
-        b.aux[0] = a.zp_out ? (void*)a.zp_out : (void*)a.e8m0_out;
-        hipLaunchKernelGGL((k_grouped_batch<Policy, DT, VPG>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+        batch_set(b, 0, 0, nvec, a.w, a.packed, a.scale_out, a.zp_out ? (void*)a.zp_out : (void*)a.e8m0_out);
+        (void)launch_batch_kernel<Policy, DT, VPG>(b, s);
     } else {
         hipLaunchKernelGGL((k_grouped<Policy, DT, VPG, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     }

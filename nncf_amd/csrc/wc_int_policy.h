@@ -10,12 +10,16 @@ namespace wc {
 //     t = RN(w*r),  t2 = RN(t + z),  k = rne(t2).
 // With x = RN(w/s), x2 = RN(x + z):  |t - x| <= 3.01*2^-24*|t|  and  |t2 - x2| <= 3.01*2^-24*(|t| + |t2|)
 // (one rounding each in r, w*r and w/s, plus the two sums' roundings), so k can differ from the reference
-// only if a half-integer lies within that distance of t2.  Such elements (|t2 - k| > 0.5 - 2^-21*(|t|+|t2|),
+// only if a half-integer lies within that distance of t2.  (r itself comes from v_rcp_f32 plus one Newton step:
+// within 0.5 ulp + 2^-46 of 1/s, which the 0.01 of slack in the 3.01 absorbs.)  Such elements (|t2 - k| > 0.5 - 2^-21*(|t|+|t2|),
 // probability ~2^-18 per int4 element), NaN/inf intermediates and groups whose scale is outside
 // [2^-100, 2^100] are recomputed with the IEEE divide, so the result is bit-exact by construction.
 constexpr float kTieMargin = 4.76837158203125e-07f;  // 2^-21
 
-struct IntPolicy {
+// MODE >= 0 fixes the mode at compile time (the multi-tensor kernel: levels and branches fold away);
+// MODE == -1 reads it from GroupArgs.
+template <int MODE>
+struct IntPolicyT {
     IntMode m;
     float pack_bias;  // 8 * 0x1111 for signed nibbles, 0 for unsigned
     struct Stat {
@@ -27,7 +31,7 @@ struct IntPolicy {
         bool has_zp, fast;
     };
     static __device__ __forceinline__ void init_shared(float*) {}
-    __device__ __forceinline__ IntPolicy(const GroupArgs& a, const float*) : m(int_mode(a.mode)) {
+    __device__ __forceinline__ IntPolicyT(const GroupArgs& a, const float*) : m(int_mode(MODE >= 0 ? MODE : a.mode)) {
         pack_bias = m.asym ? 0.0f : 34952.0f;
     }
     __device__ __forceinline__ Stat stat_init() const { return {__builtin_inff(), -__builtin_inff()}; }
@@ -60,7 +64,8 @@ struct IntPolicy {
         s.hi = block_allreduce<4>(s.hi, OpMax(), smem + 8);
     }
     __device__ __forceinline__ void finish(Par& p) const {
-        p.r = 1.0f / p.scale;
+        const float r0 = __builtin_amdgcn_rcpf(p.scale);
+        p.r = fmaf(fmaf(-p.scale, r0, 1.0f), r0, r0);
         const float as = fabsf(p.scale);
         p.fast = (as >= 7.888609052210118e-31f) && (as <= 1.2676506002282294e+30f);  // [2^-100, 2^100]
         if (m.bits == 4 && !(fabsf(p.zpf) <= 15.0f)) p.fast = false;  // the 4-bit constant margins assume |z| <= 15
@@ -236,6 +241,15 @@ struct IntPolicy {
         store_codes<E>(a, k, v * E);
         store_dq<E>(a, p, k, v * E);
     }
+    // multi-tensor kernel: NE consecutive elements of one lane -> NE/8 dwords of nibbles (f is clobbered)
+    template <int NE, int GPL>
+    __device__ __forceinline__ void pack_lane(const Par* par, float* f, uint32_t* out) const {
+        constexpr int SG = NE / GPL;
+#pragma unroll
+        for (int gi = 0; gi < GPL; ++gi) quant_n<SG>(par[gi], f + gi * SG, f + gi * SG);
+#pragma unroll
+        for (int j = 0; j < NE / 8; ++j) out[j] = nibbles8(f + 8 * j);
+    }
     // grouped kernel: NE consecutive elements of one lane, covering GPL whole groups (or a part of one)
     template <int NE, int GPL, bool NT>
     __device__ __forceinline__ void emit_lane(const GroupArgs& a, const Par* par, float* f, int64_t e0) const {
@@ -247,5 +261,6 @@ struct IntPolicy {
         for (int gi = 0; gi < GPL; ++gi) store_dq<SG>(a, par[gi], f + gi * SG, e0 + gi * SG);
     }
 };
+using IntPolicy = IntPolicyT<-1>;
 
 }  // namespace wc

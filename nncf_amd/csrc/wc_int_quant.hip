@@ -43,6 +43,14 @@ static int int_quantize_impl(const void* weight, int w_dtype, int64_t outer, int
         set_error("int_quantize: packed_out needs an even number of elements");
         return NNCF_AMD_ERR_BAD_ARG;
     }
+    // data-free packed 4-bit compression of one tensor: the mode-specialised multi-tensor kernel with one item
+    if (m.bits == 4 && inner == 1 && packed_out && scale_out && !scale_in && !codes_out && !dq_out && (!m.asym || zp_out)) {
+        BatchItem it = {weight, outer, r, packed_out, scale_out, m.asym ? (void*)zp_out : nullptr};
+        int vpg;
+        if (batch_fits<IntPolicy>(w_dtype, &it, 1, group_size, &vpg))
+            return m.asym ? run_batch<IntPolicyT<NNCF_AMD_INT4_ASYM>>(w_dtype, &it, 1, vpg, mode, "int_quantize", s)
+                          : run_batch<IntPolicyT<NNCF_AMD_INT4_SYM>>(w_dtype, &it, 1, vpg, mode, "int_quantize", s);
+    }
     GroupArgs a = {};
     a.w = weight;
     a.scale_in = scale_in;
@@ -95,7 +103,11 @@ extern "C" int nncf_amd_int_quantize_batched(int n, const void* const* weights_h
         bool fits = batch_fits<IntPolicy>(w_dtype, items.data(), n, group_size, &vpg);
         if (fits && m.asym)
             for (int i = 0; i < n; ++i) fits = fits && items[i].aux != nullptr;
-        if (fits) return run_batch<IntPolicy>(w_dtype, items.data(), n, vpg, mode, "int_quantize_batched", (hipStream_t)stream);
+        if (fits) {
+            const char* what = "int_quantize_batched";
+            return m.asym ? run_batch<IntPolicyT<NNCF_AMD_INT4_ASYM>>(w_dtype, items.data(), n, vpg, mode, what, (hipStream_t)stream)
+                          : run_batch<IntPolicyT<NNCF_AMD_INT4_SYM>>(w_dtype, items.data(), n, vpg, mode, what, (hipStream_t)stream);
+        }
     }
     for (int i = 0; i < n; ++i) {
         int st = int_quantize_impl(weights_host[i], w_dtype, rows_host[i], cols_host[i], 1, group_size, mode, nullptr,

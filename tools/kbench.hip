@@ -121,6 +121,19 @@ int main(int argc, char** argv) {
         double usb = ms * 1e3 / 10;
         printf("batched x%d (HBM-cold): %.2f us  in %.1f GB/s  algorithmic %.1f GB/s (%.1f%% of 8 TB/s)\n", NB, usb,
                NB * n * 2.0 / usb * 1e-3, NB * alg / usb * 1e-3, NB * alg / usb * 1e-3 / 80.0);
+        if (getenv("WC_CLK")) {
+            const int nw = 2048 * 4;
+            std::vector<uint64_t> rec(nw * 4);
+            CK(hipMemcpy(rec.data(), ss[0], rec.size() * 8, hipMemcpyDeviceToHost));
+            uint64_t t0 = ~0ull, t1 = 0;
+            for (int i = 0; i < nw; ++i) { if (rec[4 * i] < t0) t0 = rec[4 * i]; if (rec[4 * i + 1] > t1) t1 = rec[4 * i + 1]; }
+            printf("kernel span %.1f us\n", (t1 - t0) * 0.01);
+            FILE* fo = fopen(getenv("WC_CLK"), "w");
+            for (int i = 0; i < nw; ++i)
+                fprintf(fo, "%d %.2f %.2f %llu %llx\n", i, (rec[4 * i] - t0) * 0.01, (rec[4 * i + 1] - t0) * 0.01,
+                        (unsigned long long)rec[4 * i + 2], (unsigned long long)rec[4 * i + 3]);
+            fclose(fo);
+        }
         // probe over the same distinct buffers
         int64_t nvecb = n / 8;
         for (int grid : {2048, 8192}) {
