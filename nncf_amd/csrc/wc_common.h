@@ -103,6 +103,11 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+__device__ __forceinline__ float min3_abs_raw(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ float max3_abs_raw(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));

@@ -20,11 +20,19 @@ __device__ static const float kE2M1Q[15] = {-6.0f, -4.0f, -3.0f, -2.0f, -1.5f, -
 // index in kE2M1Q -> OCP e2m1 bit pattern (sign<<3 | exp<<1 | man); the reference's single (negative) zero -> 0b0000
 __device__ static const uint8_t kE2M1Code[15] = {15, 14, 13, 12, 11, 10, 9, 0, 1, 2, 3, 4, 5, 6, 7};
 
-// LDS table layout (floats): [0,40) bucket centers, [40,80) bucket base index (as int bits), [80,96) quantiles,
+// LDS table layout (floats): [0,80) per bucket the pair (center, base index as int bits), [80,96) quantiles,
 // [96,112) codes (as int bits)
-constexpr int kLutCenter = 0, kLutBase = 40, kLutQ = 80, kLutCode = 96;
+constexpr int kLutPair = 0, kLutQ = 80, kLutCode = 96;
 
-template <bool NF4>
+// Fast exact NF4 (multi-tensor kernel).  The reference takes n = RN(w/s) per element and counts the centers below
+// n.  Here r ~ 1/s once per group (v_rcp_f32 + one Newton step) and t = RN(w*r): |t - n| <= 3.01*2^-24*|t| < 2^-22
+// (|t| <= 1), so the count can differ only if a center lies that close to t.  No center is within 0.02/16 of a
+// bucket boundary (table property, checked by tests/test_oracle_known_answers.py), so testing the center of t's
+// own bucket is enough; elements inside the margin are recomputed with the IEEE divide.
+constexpr float kNF4Margin = 2.384185791015625e-07f;  // 2^-22
+
+// MODE >= 0 fixes the mode at compile time (multi-tensor kernel); -1 reads it from GroupArgs.
+template <bool NF4, int MODE = -1>
 struct FloatPolicy {
     // bucket = clamp(floor(n * K) + OFF, 0, NB-1)
     static constexpr float K = NF4 ? 16.0f : 2.0f;
@@ -38,6 +46,8 @@ struct FloatPolicy {
     };
     struct Par {
         float scale;
+        float r;    // ~1/scale (NF4 fast path)
+        bool fast;  // scale inside [2^-100, 2^100]
     };
 
     static __device__ __forceinline__ float center(int j) {
@@ -59,15 +69,15 @@ struct FloatPolicy {
                 if (bj < t) ++base;
                 if (bj == t) c = center(j);
             }
-            lds[kLutCenter + t] = c;
-            lds[kLutBase + t] = __builtin_bit_cast(float, base);
+            lds[kLutPair + 2 * t] = c;
+            lds[kLutPair + 2 * t + 1] = __builtin_bit_cast(float, base);
         }
         if (t < NQ) {
             lds[kLutQ + t] = NF4 ? kNF4Q[t] : kE2M1Q[t];
             lds[kLutCode + t] = __builtin_bit_cast(float, NF4 ? t : (int)kE2M1Code[t]);
         }
     }
-    __device__ __forceinline__ FloatPolicy(const GroupArgs& a, const float* lds) : lut(lds), mode(a.mode) {}
+    __device__ __forceinline__ FloatPolicy(const GroupArgs& a, const float* lds) : lut(lds), mode(MODE >= 0 ? MODE : a.mode) {}
     __device__ __forceinline__ Stat stat_init() const { return {0.0f}; }
     __device__ __forceinline__ void stat_add(Stat& s, float f) const { s.amax = fmaxf(s.amax, fabsf(f)); }
     template <int E>
@@ -89,17 +99,70 @@ struct FloatPolicy {
     template <int NE, int GPL>
     __device__ __forceinline__ void pack_lane(const Par* par, float* f, uint32_t* out) const {
         constexpr int SG = NE / GPL;
+        if constexpr (!NF4 && MODE == NNCF_AMD_MXFP4) {
+            // The scale is a power of two, so w/scale is exact and v_cvt_scalef32_pk_fp4_f32 (divide by the scale's
+            // power of two, round to nearest even in e2m1, saturate at +-6) IS the reference's rounding
+            // (weight_lowering.py:577-583: ties go to the even mantissa).  Its -0 (code 8) becomes the
+            // reference's single zero (code 0).
 #pragma unroll
-        for (int j = 0; j < NE / 8; ++j) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                int code;
-                float val;
-                quant(f[8 * j + q], par[(8 * j + q) / SG], code, val);
-                w |= (uint32_t)code << (4 * q);
+            for (int j = 0; j < NE / 8; ++j) {
+                const float* e = f + 8 * j;
+                uint32_t w = 0;
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, e[0], e[1], par[(8 * j + 0) / SG].scale, 0);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, e[2], e[3], par[(8 * j + 2) / SG].scale, 1);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, e[4], e[5], par[(8 * j + 4) / SG].scale, 2);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, e[6], e[7], par[(8 * j + 6) / SG].scale, 3);
+                const uint32_t mag = w & 0x77777777u;
+                const uint32_t nz = (mag | (mag >> 1) | (mag >> 2)) & 0x11111111u;  // bit 0 of a nibble: magnitude != 0
+                out[j] = w & (0x77777777u | (nz << 3));
             }
-            out[j] = w;
+        } else if constexpr (NF4) {
+#pragma unroll
+            for (int j = 0; j < NE / 8; ++j) {
+                int idx[8];
+                float d[8];
+                bool fast = true;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const Par& p = par[(8 * j + q) / SG];
+                    fast = fast && p.fast;
+                    const float t = f[8 * j + q] * p.r;
+                    int bk = __float2int_rd(t * K) + OFF;
+                    bk = bk < 0 ? 0 : (bk > NB - 1 ? NB - 1 : bk);
+                    const float2 pr = *(const float2*)(lut + kLutPair + 2 * bk);
+                    idx[q] = __builtin_bit_cast(int, pr.y) + (t > pr.x ? 1 : 0);
+                    d[q] = t - pr.x;
+                }
+                float viol = __builtin_inff();
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) viol = min3_abs_raw(viol, d[q], d[q + 1]);
+                if (!fast || !(viol > kNF4Margin)) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (!fast || !(fabsf(d[q]) > kNF4Margin)) {
+                            float val;
+                            quant(f[8 * j + q], par[(8 * j + q) / SG], idx[q], val);
+                        }
+                    }
+                }
+                uint32_t w = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w |= (uint32_t)idx[q] << (4 * q);
+                out[j] = w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NE / 8; ++j) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    int code;
+                    float val;
+                    quant(f[8 * j + q], par[(8 * j + q) / SG], code, val);
+                    w |= (uint32_t)code << (4 * q);
+                }
+                out[j] = w;
+            }
         }
     }
     template <int NE, int GPL, bool NT>
@@ -175,9 +238,18 @@ struct FloatPolicy {
             k = k < -127 ? -127 : (k > 127 ? 127 : k);
             sc = ldexpf(1.0f, k);
         }
-        return {sc};
+        return with_reciprocal(sc);
     }
-    __device__ __forceinline__ Par load(const GroupArgs& a, int64_t g) const { return {a.scale_in[g]}; }
+    __device__ __forceinline__ Par with_reciprocal(float sc) const {
+        Par p;
+        p.scale = sc;
+        const float r0 = __builtin_amdgcn_rcpf(sc);
+        p.r = fmaf(fmaf(-sc, r0, 1.0f), r0, r0);
+        const float as = fabsf(sc);
+        p.fast = (as >= 7.888609052210118e-31f) && (as <= 1.2676506002282294e+30f);  // [2^-100, 2^100]
+        return p;
+    }
+    __device__ __forceinline__ Par load(const GroupArgs& a, int64_t g) const { return with_reciprocal(a.scale_in[g]); }
     template <bool NT>
     __device__ __forceinline__ void store(const GroupArgs& a, int64_t g, const Par& p) const {
         if (a.scale_out) st<NT>(a.scale_out + g, p.scale);
@@ -191,7 +263,7 @@ struct FloatPolicy {
     __device__ __forceinline__ void quant(float w, const Par& p, int& code, float& value) const {
         const float n = w / p.scale;  // weight_lowering.py:626
         const int b = bucket_of(n);
-        int idx = __builtin_bit_cast(int, lut[kLutBase + b]) + (n > lut[kLutCenter + b] ? 1 : 0);
+        int idx = __builtin_bit_cast(int, lut[kLutPair + 2 * b + 1]) + (n > lut[kLutPair + 2 * b] ? 1 : 0);
         if constexpr (!NF4) {
             // weight_lowering.py:577-583
             const int r = idx + 1 > NQ - 1 ? NQ - 1 : idx + 1;

@@ -10,6 +10,14 @@
 
 #include "wc_float_policy.h"
 
+namespace wc {
+static int run_float_batch(int w_dtype, const BatchItem* items, int n, int vpg, int mode, const char* what, hipStream_t s) {
+    if (mode == NNCF_AMD_NF4) return run_batch<FloatPolicy<true>>(w_dtype, items, n, vpg, mode, what, s);
+    if (mode == NNCF_AMD_MXFP4) return run_batch<FloatPolicy<false, NNCF_AMD_MXFP4>>(w_dtype, items, n, vpg, mode, what, s);
+    return run_batch<FloatPolicy<false>>(w_dtype, items, n, vpg, mode, what, s);
+}
+}  // namespace wc
+
 extern "C" int nncf_amd_float_quantize(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
                                        int64_t group_size, int mode, const float* scale_in, float* values_out,
                                        uint8_t* codes_out, uint8_t* packed_out, float* scale_out,
@@ -29,6 +37,13 @@ extern "C" int nncf_amd_float_quantize(const void* weight, int w_dtype, int64_t 
     if (scale_e8m0_out && mode != NNCF_AMD_MXFP4) {
         set_error("float_quantize: scale_e8m0_out is for MXFP4 only");
         return NNCF_AMD_ERR_BAD_ARG;
+    }
+    // data-free packed compression of one tensor: the mode-specialised multi-tensor kernel with one item
+    if (inner == 1 && packed_out && scale_out && !scale_in && !codes_out && !values_out && !dq_out) {
+        BatchItem it = {weight, outer, r, packed_out, scale_out, (void*)scale_e8m0_out};
+        int vpg;
+        if (batch_fits<FloatPolicy<true>>(w_dtype, &it, 1, group_size, &vpg))
+            return run_float_batch(w_dtype, &it, 1, vpg, mode, "float_quantize", (hipStream_t)stream);
     }
     GroupArgs a = {};
     a.w = weight;
@@ -72,11 +87,7 @@ extern "C" int nncf_amd_float_quantize_batched(int n, const void* const* weights
                         scale_e8m0_out_host ? (void*)scale_e8m0_out_host[i] : nullptr};
         int vpg;
         if (batch_fits<FloatPolicy<true>>(w_dtype, items.data(), n, group_size, &vpg)) {
-            if (mode == NNCF_AMD_NF4)
-                return run_batch<FloatPolicy<true>>(w_dtype, items.data(), n, vpg, mode, "float_quantize_batched",
-                                                    (hipStream_t)stream);
-            return run_batch<FloatPolicy<false>>(w_dtype, items.data(), n, vpg, mode, "float_quantize_batched",
-                                                 (hipStream_t)stream);
+            return run_float_batch(w_dtype, items.data(), n, vpg, mode, "float_quantize_batched", (hipStream_t)stream);
         }
     }
     for (int i = 0; i < n; ++i) {

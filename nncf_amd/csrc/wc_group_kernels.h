@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
     constexpr int TILE = 64 * VPL;                      // vectors per tile
     static_assert(LPG <= 64, "group must fit in one wave");
     __shared__ Vec16 stage[4][TILE];
-    __shared__ float lds[kPolicyLds];
+    __shared__ __align__(16) float lds[kPolicyLds];
     Policy::init_shared(lds);
     __syncthreads();
     const Policy pol(a, lds);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     constexpr int TILE = 64 * VPL;
     constexpr int NW = NE / 8;  // packed dwords per lane
     __shared__ Vec16 stage[4][TILE];
-    __shared__ float lds[kPolicyLds];
+    __shared__ __align__(16) float lds[kPolicyLds];
     Policy::init_shared(lds);
     __syncthreads();
     GroupArgs o = {};
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
     uint32_t t = cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
     if (t >= hi) return;  // (a wave makes exactly one failing claim: the host's running counter values rely on it)
-#ifdef WC_CLK
+#ifdef WC_CLK  // developer build: per-wave start/end times into scale[0] (read back by tools/kbench.hip, WC_CLK=<file>)
     const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     int i = 0;
@@ -409,13 +409,6 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
         const bool live = (uint32_t)(lane * VPL) < in_tile;  // rem % VPL == 0 (host): a lane is all live or all dead
         const uint32_t v0 = lt * TILE + lane * VPL;          // first vector of this lane, < 2^30
         const uint32_t g0 = v0 / VPG;
-#if defined(WC_EXP) && WC_EXP == 1
-#pragma unroll
-        for (int q = 0; q < NW; ++q) pend[q] = 0;
-#pragma unroll
-        for (int q = 0; q < NE; ++q) pend[q % NW] ^= __float_as_uint(f[q]);
-        (void)g0;
-#else
         typename Policy::Par par[GPL];
 #pragma unroll
         for (int gi = 0; gi < GPL; ++gi) {
@@ -429,7 +422,6 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
             for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(o, g0 + gi, par[gi]);
         }
         pol.template pack_lane<NE, GPL>(par, f, pend);
-#endif
         pend_dst = live ? cur.packed + (uint64_t)v0 * (E / 2) : nullptr;
         if (tn >= hi) break;
         t = tn;
@@ -599,7 +591,7 @@ template <typename Policy, int DT, int TEAM, int KEEP>
 __global__ __launch_bounds__(256) void k_row(GroupArgs a, int64_t vpg) {
     constexpr int E = Elem<DT>::kPerVec;
     constexpr int TEAMS_PER_BLOCK = 256 / TEAM;
-    __shared__ float lds[kPolicyLds];
+    __shared__ __align__(16) float lds[kPolicyLds];
     __shared__ float smem[16];
     Policy::init_shared(lds);
     __syncthreads();
@@ -672,7 +664,7 @@ __global__ __launch_bounds__(256) void k_row(GroupArgs a, int64_t vpg) {
 // `inner` positions, so inner > 1 layouts (reduction along a non-last axis) stay coalesced.
 template <typename Policy, int DT>
 __global__ __launch_bounds__(256) void k_generic(GroupArgs a) {
-    __shared__ float lds[kPolicyLds];
+    __shared__ __align__(16) float lds[kPolicyLds];
     Policy::init_shared(lds);
     __syncthreads();
     const Policy pol(a, lds);

@@ -118,3 +118,64 @@ def test_mx_scale_boundaries_dense():
     rv, rs, _ = O.compress_weight(w32, (1,), "mxfp4", 32)
     assert_equal_nan(host(cw.scale), rs, "mx scale")
     assert_equal_nan(host(cw.tensor), rv, "mx values")
+
+
+def _unpack_nibbles(packed):
+    p = host(packed).ravel()
+    return np.stack([p & 15, p >> 4], axis=1).ravel()
+
+
+def _adversarial_groups(mode, gs, rng, big=2.0 ** 20):
+    """Groups whose normalised weights sit on / within a few ulp of every decision boundary, for scales that
+    are and are not powers of two; plus zeros, negative underflow (the reference has a single zero) and saturation."""
+    centers = O.CENTER_OF_NF4_QUANTILES if mode == "nf4" else O.CENTER_OF_F4E2M1_QUANTILES
+    top = np.float32(1.0 if mode == "nf4" else 6.0)
+    anchors = [1.0, 0.75, 3.1415927, 1e-3, 1.9999999, 2.0 ** -12 * 1.2345, 37.5, big, 5e-8]
+    rows = []
+    for a in anchors:
+        amax = np.float32(a) * top
+        scale = np.float32(a) if mode == "nf4" else np.float32(2.0) ** np.ceil(np.log2(np.float64(np.float32(amax / np.float32(6)))))
+        cand = []
+        for c in np.concatenate([centers, [0.0]]):
+            x = np.float32(np.float32(c) * np.float32(scale))
+            lo = up = x
+            cand.append(x)
+            for _ in range(3):
+                lo = np.nextafter(lo, np.float32(-np.inf))
+                up = np.nextafter(up, np.float32(np.inf))
+                cand += [lo, up]
+        cand += [np.float32(-1e-9) * scale, np.float32(1e-9) * scale, np.float32(-0.0), -amax, amax * np.float32(0.999999)]
+        cand = np.array(cand, np.float32)
+        cand = cand[np.abs(cand) <= amax]
+        n_rows = -(-cand.size // (gs - 1))
+        buf = np.zeros((n_rows, gs), np.float32)
+        buf[:, 0] = amax  # pins the group scale
+        body = np.resize(cand, n_rows * (gs - 1)).reshape(n_rows, gs - 1)
+        buf[:, 1:] = body
+        rows.append(buf)
+    w = np.concatenate(rows)
+    extra = (rng.standard_normal((7, gs)) * 0.05).astype(np.float32)
+    return np.concatenate([w, extra])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("mode", ["nf4", "mxfp4"])
+def test_packed_fast_paths_adversarial(mode, dtype):
+    """The multi-tensor kernel's NF4 reciprocal fast path (margin + exact redo) and MXFP4 hardware e2m1 convert
+    against the oracle, on weights built to sit on the decision boundaries."""
+    from nncf_amd import weight_lowering as wl
+    rng = np.random.default_rng(7)
+    gs = 32
+    w32 = representable(_adversarial_groups(mode, gs, rng, big=2.0 ** 12 if dtype == "f16" else 2.0 ** 20), dtype)  # no inf: NaN is outside the contract
+    w32 = w32.reshape(-1, 4 * gs) if w32.shape[0] % 4 == 0 else np.concatenate([w32, w32[: 4 - w32.shape[0] % 4]]).reshape(-1, 4 * gs)
+    lut = O.NF4_QUANTILES if mode == "nf4" else O.E2M1_VALUE_OF_CODE
+    ws = [w32, w32[:5], np.ascontiguousarray(w32[::-1])]
+    got = wl.compress_weights_packed_batched([to_dev(x, dtype) for x in ws], _cfg(mode, gs), want_e8m0=(mode == "mxfp4"))
+    for x, cw in zip(ws, got):
+        rv, rs, _ = O.compress_weight(x, (1,), mode, gs)
+        assert_equal_nan(host(cw.scale).reshape(rs.shape), rs, "scale")
+        assert np.array_equal(lut[_unpack_nibbles(cw.tensor)], rv.ravel()), f"{mode} {dtype} values"
+        if mode == "mxfp4":
+            assert np.array_equal(np.ldexp(np.float32(1), host(cw.codebook).astype(np.int32) - 127).reshape(rs.shape), rs)
+    single = wl.compress_weight_packed(to_dev(w32, dtype), (1,), _cfg(mode, gs))
+    assert np.array_equal(host(single.tensor), host(got[0].tensor))

@@ -227,3 +227,27 @@ def test_batched_matches_single_and_oracle(mode, gs, dtype):
             assert np.array_equal(lut[codes], rc.ravel())
             if mode == "mxfp4":
                 assert np.array_equal(np.ldexp(np.float32(1), host(cw.codebook).astype(np.int32).ravel() - 127), rs.ravel())
+
+
+def test_claim_counters_survive_many_launches():
+    """The multi-tensor kernel hands tiles out through counters that are never reset (the host tracks their running
+    values per slot): many launches of changing sizes, cycling every slot several times, must keep giving the same
+    answer -- a drifted counter would skip or repeat tiles."""
+    from nncf_amd import weight_lowering as wl
+    torch.manual_seed(1)
+    cfg = _cfg("int4_sym", 128)
+    sets = [[(torch.randn(r, c, device="cuda") * 0.02).to(torch.bfloat16) for r, c in shapes]
+            for shapes in ([(4096, 4096), (1024, 4096), (14336, 4096)], [(8, 128)], [(3, 256), (515, 1024), (64, 2048)],
+                           [(2048, 8192)] * 5)]
+    want = [[(cw.tensor.clone(), cw.scale.clone()) for cw in wl.compress_weights_packed_batched(ws, cfg)] for ws in sets]
+    for it in range(120):
+        k = it % len(sets)
+        got = wl.compress_weights_packed_batched(sets[k], cfg)
+        if it % 7 == 0 or it > 100:
+            for (t, s), cw in zip(want[k], got):
+                assert torch.equal(t, cw.tensor) and torch.equal(s, cw.scale), f"iteration {it}"
+    # a tensor with the sentinel pattern: every packed byte must have been written exactly by its own tile
+    w = sets[0][2]
+    out = wl.compress_weight_packed(w, (1,), cfg)
+    ref = wl.compress_weight(w, (1,), cfg)
+    assert torch.equal(wl.pack_int4(ref.tensor), out.tensor)

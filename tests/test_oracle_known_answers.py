@@ -151,3 +151,12 @@ def test_mixed_precision_literals():
 def test_x86_int32_overflow_rule():
     v = np.array([2.5e9, -2.5e9, np.nan, 3.7, -3.7, 2147483520.0], np.float32)
     assert O.x86_cvtt_int32(v).tolist() == [-2 ** 31, -2 ** 31, -2 ** 31, 3, -3, 2147483520]
+
+
+def test_nf4_centers_stay_clear_of_bucket_boundaries():
+    """The HIP fast path (wc_float_policy.h, kNF4Margin) looks only at the center of t's own 1/16-wide bucket:
+    sound as long as no center sits within the rounding margin of a bucket boundary."""
+    c = np.asarray(O.CENTER_OF_NF4_QUANTILES, dtype=np.float64) * 16.0
+    assert np.min(np.abs(c - np.round(c))) > 0.02
+    buckets = np.floor(c).astype(int)
+    assert len(set(buckets.tolist())) == len(buckets)  # at most one center per bucket
