@@ -440,26 +440,22 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
 #endif
 }
 
-// grid of a multi-tensor launch: one resident set of blocks (never a second, under-occupied round), at most one
-// wave per tile.
-template <typename Policy, int DT, int VPG>
-static int batch_grid(int64_t tiles) {
-    static int resident = 0;  // blocks the device holds at once
-    if (resident == 0) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_grouped_batch<Policy, DT, VPG>, 256, 0) != hipSuccess ||
-            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
-            resident = kBatchGrid;
-        else
-            resident = per_cu * prop.multiProcessorCount;
-    }
-    const int64_t blocks = (tiles + 3) / 4;
-    return (int)(blocks < resident ? blocks : resident);
+// blocks of `kernel` the device holds at once (cached by the caller per kernel instantiation)
+template <typename Kernel>
+static int resident_blocks(Kernel kernel) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
+        return kBatchGrid;
+    return per_cu * prop.multiProcessorCount;
 }
 
-template <typename Policy, int DT, int VPG>
-static hipError_t launch_batch_kernel(BatchArgs& b, hipStream_t s) {
+// Launches a kernel whose teams (`teams_per_block` per block) claim work units: takes a counter slot, fills in
+// the parts and the counters' current values, launches, and advances the host's copy of the counters (every team
+// stops at its first failed claim, so a launch adds units-in-part + teams-on-part to each counter).
+template <typename Kernel>
+static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block, BatchArgs& b, hipStream_t s) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -467,8 +463,7 @@ static hipError_t launch_batch_kernel(BatchArgs& b, hipStream_t s) {
     uint32_t* sym = nullptr;
     e = hipGetSymbolAddress((void**)&sym, HIP_SYMBOL(g_claim));
     if (e != hipSuccess) return e;
-    const uint32_t tiles = b.tile_start[b.n];
-    const int blocks = batch_grid<Policy, DT, VPG>(tiles);
+    const uint32_t units = b.tile_start[b.n];
     if (blocks < 1) return hipSuccess;
     int lg = 0;
     while ((16 << lg) <= blocks && (2 << lg) <= kClaimGroupsUsed) ++lg;  // at least one octet of blocks per part
@@ -483,16 +478,25 @@ static hipError_t launch_batch_kernel(BatchArgs& b, hipStream_t s) {
     uint32_t seen = 0;
     for (int g = 0; g < groups; ++g) {
         b.base[g] = shadow[g];
-        b.part_lo[g] = (uint32_t)((uint64_t)tiles * seen / (uint32_t)blocks);
+        b.part_lo[g] = (uint32_t)((uint64_t)units * seen / (uint32_t)blocks);
         seen += blocks_on[g];
     }
-    b.part_lo[groups] = tiles;
-    hipLaunchKernelGGL((k_grouped_batch<Policy, DT, VPG>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+    b.part_lo[groups] = units;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
     e = hipPeekAtLastError();
     if (e != hipSuccess) return e;
-    // the launch adds tiles-in-part + waves-on-part to each counter (every wave stops at its first failed claim)
-    for (int g = 0; g < groups; ++g) shadow[g] += (b.part_lo[g + 1] - b.part_lo[g]) + 4u * blocks_on[g];
+    for (int g = 0; g < groups; ++g)
+        shadow[g] += (b.part_lo[g + 1] - b.part_lo[g]) + (uint32_t)teams_per_block * blocks_on[g];
     return hipSuccess;
+}
+
+// grid of a multi-tensor launch: one resident set of blocks (never a second, under-occupied round), at most one
+// wave per tile.
+template <typename Policy, int DT, int VPG>
+static hipError_t launch_batch_kernel(BatchArgs& b, hipStream_t s) {
+    static const int resident = resident_blocks(k_grouped_batch<Policy, DT, VPG>);
+    const int64_t blocks = ((int64_t)b.tile_start[b.n] + 3) / 4;
+    return launch_claimed(k_grouped_batch<Policy, DT, VPG>, (int)(blocks < resident ? blocks : resident), 4, b, s);
 }
 
 template <typename Policy, int DT, int VPG>

@@ -10,11 +10,10 @@ namespace wc {
 //     t = RN(w*r),  t2 = RN(t + z),  k = rne(t2).
 // With x = RN(w/s), x2 = RN(x + z):  |t - x| <= 3.01*2^-24*|t|  and  |t2 - x2| <= 3.01*2^-24*(|t| + |t2|)
 // (one rounding each in r, w*r and w/s, plus the two sums' roundings), so k can differ from the reference
-// only if a half-integer lies within that distance of t2.  (r itself comes from v_rcp_f32 plus one Newton step:
+// only if a half-integer lies within that distance of t2 (a constant per mode, see quant_n).  (r itself comes from v_rcp_f32 plus one Newton step:
 // within 0.5 ulp + 2^-46 of 1/s, which the 0.01 of slack in the 3.01 absorbs.)  Such elements (|t2 - k| > 0.5 - 2^-21*(|t|+|t2|),
-// probability ~2^-18 per int4 element), NaN/inf intermediates and groups whose scale is outside
+// probability ~2^-17 per int4 element), NaN/inf intermediates and groups whose scale is outside
 // [2^-100, 2^100] are recomputed with the IEEE divide, so the result is bit-exact by construction.
-constexpr float kTieMargin = 4.76837158203125e-07f;  // 2^-21
 
 // MODE >= 0 fixes the mode at compile time (the multi-tensor kernel: levels and branches fold away);
 // MODE == -1 reads it from GroupArgs.
@@ -68,7 +67,7 @@ struct IntPolicyT {
         p.r = fmaf(fmaf(-p.scale, r0, 1.0f), r0, r0);
         const float as = fabsf(p.scale);
         p.fast = (as >= 7.888609052210118e-31f) && (as <= 1.2676506002282294e+30f);  // [2^-100, 2^100]
-        if (m.bits == 4 && !(fabsf(p.zpf) <= 15.0f)) p.fast = false;  // the 4-bit constant margins assume |z| <= 15
+        if (!(fabsf(p.zpf) <= m.level_high)) p.fast = false;  // the constant tie margins assume |z| <= levels
     }
     __device__ __forceinline__ Par compute(const Stat& s) const {
         Par p;
@@ -111,7 +110,7 @@ struct IntPolicyT {
     }
     __device__ __forceinline__ int nibble(int code) const { return code + (m.asym ? 0 : 8); }
 
-    // k[i] <- clip(rne(w/s [+ z])) for N elements sharing one parameter set; exact (see kTieMargin above).
+    // k[i] <- clip(rne(w/s [+ z])) for N elements sharing one parameter set; exact (see the header comment).
     // f and k may alias: elements are processed in chunks of C whose inputs stay intact until the chunk's
     // rare exact re-computation has been decided.  The fast path's t2 = fma(w, r, z) (one rounding) is
     // covered by the same error bound as RN(RN(w*r) + z).  The tie test keeps a running maximum of the
@@ -120,30 +119,22 @@ struct IntPolicyT {
     __device__ __forceinline__ void quant_n(const Par& p, const float* f, float* k) const {
         constexpr int C = N < 8 ? N : 8;
         const float z = p.has_zp ? p.zpf : 0.0f;
-        // 4-bit: |t2| <= 16 and |t| <= 31 wherever the clip does not decide anyway -> constant margins
-        //   sym : 3.01*2^-24*16 < 2^-18        asym: 3.01*2^-24*(31+16) < 2^-16
-        const float c4 = p.has_zp ? 0.5f - 1.52587890625e-05f : 0.5f - 3.814697265625e-06f;
+        // Wherever the clip does not decide anyway, |t2| <= levels + 1.5 and |w*r| <= |t2| + |z| with |z| <= levels
+        // (finish() clears `fast` otherwise), so the error bound -- 3.01*2^-24*|t2| without a zero point,
+        // 2^-24*(2.01*|w*r| + 2*|t2|) with one -- is a constant per mode:
+        //   4-bit sym 1.6e-6 < 2^-18, asym 5.7e-6 < 2^-16;   8-bit sym 2.3e-5 < 2^-15, asym 9.2e-5 < 2^-12
+        const float margin = m.bits == 4 ? (p.has_zp ? 1.52587890625e-05f : 3.814697265625e-06f)
+                                         : (p.has_zp ? 2.44140625e-04f : 3.0517578125e-05f);
+        const float lim = 0.5f - margin;
 #pragma unroll
         for (int c0 = 0; c0 < N; c0 += C) {
             float kc[C], d[C];
-            if (m.bits == 4) {
 #pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    const float t2 = fmaf(f[c0 + i], p.r, z);
-                    const float kk = rintf(t2);
-                    d[i] = t2 - kk;
-                    kc[i] = __builtin_amdgcn_fmed3f(kk, m.level_low, m.level_high);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    const float t = f[c0 + i] * p.r;
-                    const float t2 = t + z;
-                    const float kk = rintf(t2);
-                    // violation measure: |t2-kk| + (|t|+|t2|)*margin must stay <= 0.5
-                    d[i] = fmaf(fabsf(t) + fabsf(t2), kTieMargin, fabsf(t2 - kk));
-                    kc[i] = __builtin_amdgcn_fmed3f(kk, m.level_low, m.level_high);
-                }
+            for (int i = 0; i < C; ++i) {
+                const float t2 = fmaf(f[c0 + i], p.r, z);
+                const float kk = rintf(t2);
+                d[i] = t2 - kk;
+                kc[i] = __builtin_amdgcn_fmed3f(kk, m.level_low, m.level_high);
             }
             float viol = 0.0f;
             if constexpr (C >= 2) {
@@ -154,7 +145,6 @@ struct IntPolicyT {
             }
             // +-inf weights give d = NaN, which v_max3 drops: fine, the fast path's clip(+-inf) already equals the
             // reference's result.  NaN weights are outside the contract (the reference's cast of NaN is undefined).
-            const float lim = m.bits == 4 ? c4 : 0.5f;
             const bool redo = !p.fast || !(viol <= lim);
             if (redo) {
                 // divergent, element by element, only where the tie test failed.  Exact ties are NOT rare for
@@ -215,7 +205,7 @@ struct IntPolicyT {
         if (a.codes) {
             uint32_t* dst = (uint32_t*)((uint8_t*)a.codes + e0);
             if constexpr (N == 4) dst[0] = bytes4(k);
-            if constexpr (N == 8) *(uint2*)dst = make_uint2(bytes4(k), bytes4(k + 4));
+            if constexpr (N == 8) st<NT>((u32x2*)dst, u32x2{bytes4(k), bytes4(k + 4)});
             if constexpr (N >= 16) {
 #pragma unroll
                 for (int j = 0; j < N / 16; ++j)

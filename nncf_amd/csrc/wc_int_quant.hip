@@ -10,6 +10,10 @@
 
 namespace wc {
 
+// wc_int_rows.hip: whole-row groups (per-channel) over many tensors
+bool int_rows_fit(int w_dtype, const BatchItem* items, int n, int64_t group_size);
+int int_rows_run(int w_dtype, const BatchItem* items, int n, int mode, const char* what, hipStream_t s);
+
 static int int_quantize_impl(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
                              int64_t group_size, int mode, const float* scale_in, const void* zp_in, int zp_dtype,
                              void* codes_out, uint8_t* packed_out, float* scale_out, int32_t* zp_out, float* dq_out,
@@ -50,6 +54,13 @@ static int int_quantize_impl(const void* weight, int w_dtype, int64_t outer, int
         if (batch_fits<IntPolicy>(w_dtype, &it, 1, group_size, &vpg))
             return m.asym ? run_batch<IntPolicyT<NNCF_AMD_INT4_ASYM>>(w_dtype, &it, 1, vpg, mode, "int_quantize", s)
                           : run_batch<IntPolicyT<NNCF_AMD_INT4_SYM>>(w_dtype, &it, 1, vpg, mode, "int_quantize", s);
+    }
+    // data-free per-channel compression of one tensor (codes for 8-bit, nibbles for 4-bit): the row kernel
+    if (inner == 1 && scale_out && !scale_in && !dq_out && (!m.asym || zp_out) &&
+        (m.bits == 4 ? (packed_out && !codes_out) : (codes_out && !packed_out))) {
+        BatchItem it = {weight, outer, r, m.bits == 4 ? packed_out : (uint8_t*)codes_out, scale_out,
+                        m.asym ? (void*)zp_out : nullptr};
+        if (gs == r && int_rows_fit(w_dtype, &it, 1, -1)) return int_rows_run(w_dtype, &it, 1, mode, "int_quantize", s);
     }
     GroupArgs a = {};
     a.w = weight;
@@ -108,6 +119,19 @@ extern "C" int nncf_amd_int_quantize_batched(int n, const void* const* weights_h
             return m.asym ? run_batch<IntPolicyT<NNCF_AMD_INT4_ASYM>>(w_dtype, items.data(), n, vpg, mode, what, (hipStream_t)stream)
                           : run_batch<IntPolicyT<NNCF_AMD_INT4_SYM>>(w_dtype, items.data(), n, vpg, mode, what, (hipStream_t)stream);
         }
+    }
+    // per-channel groups (whole rows): the multi-tensor row kernel
+    if (n > 0 && scale_out_host && (!m.asym || zp_out_host) &&
+        (m.bits == 4 ? (packed_out_host && !codes_out_host) : (codes_out_host && !packed_out_host))) {
+        std::vector<BatchItem> items(n);
+        for (int i = 0; i < n; ++i)
+            items[i] = {weights_host[i], rows_host[i], cols_host[i],
+                        m.bits == 4 ? packed_out_host[i] : (uint8_t*)codes_out_host[i], scale_out_host[i],
+                        m.asym ? (void*)zp_out_host[i] : nullptr};
+        bool fits = int_rows_fit(w_dtype, items.data(), n, group_size);
+        if (fits && m.asym)
+            for (int i = 0; i < n; ++i) fits = fits && items[i].aux != nullptr;
+        if (fits) return int_rows_run(w_dtype, items.data(), n, mode, "int_quantize_batched", (hipStream_t)stream);
     }
     for (int i = 0; i < n; ++i) {
         int st = int_quantize_impl(weights_host[i], w_dtype, rows_host[i], cols_host[i], 1, group_size, mode, nullptr,

@@ -1,0 +1,251 @@
+// wc_row_kernels.h -- multi-tensor per-channel lowering: the quantization group is a whole row of the weight
+// (INT8 per-channel, the reference's default mode; 4-bit with group_size = -1), too long for one wave tile.
+//
+// A team (one wave for rows up to 512 vectors, one 256-thread block above) owns one row at a time, claimed from
+// the same counters as the tile kernel (wc_group_kernels.h).  The row is read ONCE, with non-temporal 16-byte
+// loads, and stays in registers (KEEP raw vectors per thread) between the min/max pass and the quantize pass;
+// what hides the load latency is occupancy (every resident wave has a whole row in flight), not a prefetch.
+// Codes leave as 8 bytes (or 4 bytes of nibbles) per lane and vector, streaming stores.
+#pragma once
+#include "wc_group_kernels.h"
+
+namespace wc {
+
+__device__ __forceinline__ Vec16 load16_nt(const Vec16* p) {
+    Vec16 v;
+    const u32x4 r = __builtin_nontemporal_load((const u32x4*)p);
+    v.w[0] = r[0];
+    v.w[1] = r[1];
+    v.w[2] = r[2];
+    v.w[3] = r[3];
+    return v;
+}
+
+// BatchArgs use: tile_start = prefix sums of ROWS, nfull[i] = vectors per row of tensor i, packed[i] = output
+// (1-byte codes or nibble-packed), scale[i], aux[i] = int32 zero points or NULL.
+template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED>
+__global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
+    constexpr int E = Elem<DT>::kPerVec;
+    __shared__ float lds[kPolicyLds];
+    __shared__ float smem[16];
+    __shared__ uint32_t claim_sh;
+    Policy::init_shared(lds);
+    __syncthreads();
+    GroupArgs o = {};
+    o.mode = b.mode;
+    const Policy pol(o, lds);
+    const int lane = threadIdx.x & 63;
+    const int tl = threadIdx.x % TEAM;  // thread inside the team
+    const uint32_t total = b.tile_start[b.n];
+    const uint32_t part = (blockIdx.x >> 3) & ((1u << b.log2_groups) - 1);
+    const uint32_t lo = b.part_lo[part], hi = b.part_lo[part + 1];
+    (void)lo;
+    (void)total;
+    uint32_t* ctr = b.ctr + part * kClaimStride;
+    const uint32_t cbase = lo - b.base[part];
+    // team-uniform claim: a wave claims for itself, a block through thread 0 and LDS
+    uint32_t claim = 0;
+    auto claim_issue = [&]() {
+        if (TEAM == 64 ? lane == 0 : threadIdx.x == 0) claim = claim_async(ctr);
+    };
+    auto claim_take = [&]() -> uint32_t {  // after the caller's vmcnt(0)
+        if constexpr (TEAM == 64) {
+            return cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+        } else {
+            if (threadIdx.x == 0) claim_sh = claim;
+            __syncthreads();
+            const uint32_t c = claim_sh;
+            __syncthreads();  // claim_sh is rewritten next round
+            return cbase + c;
+        }
+    };
+    // The claim of the next row is in flight while this one is processed; its loads are issued only afterwards
+    // (a second register set for prefetching costs more in occupancy than it gains: measured).
+    struct Row {
+        uint32_t vpr;
+        uint64_t row;
+        int i;
+    };
+    int scan = 0;
+    auto locate = [&](uint32_t r) {
+        while (r >= b.tile_start[scan + 1]) ++scan;
+        Row d;
+        d.i = scan;
+        d.vpr = b.nfull[scan];
+        d.row = r - b.tile_start[scan];
+        return d;
+    };
+    auto load_row = [&](const Row& d, Vec16* dst) {
+        const Vec16* src = (const Vec16*)b.w[d.i] + d.row * d.vpr;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const uint32_t j = tl + k * TEAM;
+            if (j < d.vpr) dst[k] = load16_nt(src + j);
+        }
+    };
+    claim_issue();
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
+    uint32_t r = claim_take();
+    if (r >= hi) return;
+    Row cd = locate(r);
+    Vec16 cur[KEEP];
+    load_row(cd, cur);
+    claim_issue();
+    for (;;) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
+        const uint32_t rn = claim_take();
+        typename Policy::Stat st = pol.stat_init();
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const uint32_t j = tl + k * TEAM;
+            __builtin_amdgcn_sched_barrier(0);
+            if (j < cd.vpr) {
+                float f[E];
+                unpack<DT>(cur[k], f);
+                pol.template stat_add_vec<E>(st, f);
+            }
+        }
+        if constexpr (TEAM == 64) pol.template stat_lanes<64>(st);
+        else pol.stat_block(st, smem);
+        const typename Policy::Par par = pol.compute(st);
+        o.scale_out = b.scale[cd.i];
+        o.zp_out = (int32_t*)b.aux[cd.i];
+        if (tl == 0) pol.template store<true>(o, (int64_t)cd.row, par);
+        if constexpr (PACKED) o.packed = b.packed[cd.i];
+        else o.codes = b.packed[cd.i];
+        // second unpack of the raw vectors (opaque, or the compiler keeps all KEEP*E floats of the first one
+        // alive across the reduction) and one vector at a time (no interleaving: registers are what buys occupancy)
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const uint32_t j = tl + k * TEAM;
+            __builtin_amdgcn_sched_barrier(0);
+            if (j < cd.vpr) {
+                Vec16 raw = cur[k];
+                asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));
+                float f[E];
+                unpack<DT>(raw, f);
+                pol.template quant_n<E>(par, f, f);
+                pol.template store_codes<E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (rn >= hi) break;
+        cd = locate(rn);
+        load_row(cd, cur);
+        claim_issue();
+    }
+}
+
+// team/keep class of a row of `vpr` 16-byte vectors; 0 = does not fit (longer than 4096 vectors)
+struct RowClass {
+    int team, keep;
+};
+static inline RowClass row_class(int64_t vpr) {
+    if (vpr <= 64) return {64, 1};
+    if (vpr <= 128) return {64, 2};
+    if (vpr <= 256) return {64, 4};
+    if (vpr <= 512) return {64, 8};
+    if (vpr <= 1024) return {256, 4};
+    if (vpr <= 2048) return {256, 8};
+    if (vpr <= 4096) return {256, 16};
+    return {0, 0};
+}
+
+template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED>
+static hipError_t launch_rows(BatchArgs& b, hipStream_t s) {
+    static const int resident = resident_blocks(k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>);
+    constexpr int TPB = 256 / TEAM;
+    const int64_t blocks = ((int64_t)b.tile_start[b.n] + TPB - 1) / TPB;
+    return launch_claimed(k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>, (int)(blocks < resident ? blocks : resident), TPB, b, s);
+}
+
+template <typename Policy, int DT, bool PACKED>
+static hipError_t dispatch_rows(RowClass c, BatchArgs& b, hipStream_t s) {
+    if (c.team == 64) {
+        switch (c.keep) {
+            case 1: return launch_rows<Policy, DT, 64, 1, PACKED>(b, s);
+            case 2: return launch_rows<Policy, DT, 64, 2, PACKED>(b, s);
+            case 4: return launch_rows<Policy, DT, 64, 4, PACKED>(b, s);
+            default: return launch_rows<Policy, DT, 64, 8, PACKED>(b, s);
+        }
+    }
+    switch (c.keep) {
+        case 4: return launch_rows<Policy, DT, 256, 4, PACKED>(b, s);
+        case 8: return launch_rows<Policy, DT, 256, 8, PACKED>(b, s);
+        default: return launch_rows<Policy, DT, 256, 16, PACKED>(b, s);
+    }
+}
+
+// Can every item run as whole-row groups?  (16-byte rows, aligned pointers, rows of at most 4096 vectors)
+static inline bool rows_fit(int w_dtype, const BatchItem* items, int n, int64_t group_size) {
+    const int eb = w_dtype == NNCF_AMD_F32 ? 4 : 2;
+    for (int i = 0; i < n; ++i) {
+        const BatchItem& it = items[i];
+        if (it.rows <= 0 || it.cols <= 0 || (group_size != -1 && group_size != it.cols)) return false;
+        if ((it.cols * eb) % 16 != 0 || row_class(it.cols * eb / 16).team == 0) return false;
+        if (it.rows > ((int64_t)1 << 30)) return false;
+        if (!is16(it.w) || !it.packed || !is16(it.packed) || !it.scale) return false;
+    }
+    return n > 0;
+}
+
+// Runs the items class by class (tensors of one team/keep class share launches of up to kMaxBatch tensors).
+template <typename Policy, bool PACKED>
+static int run_rows(int w_dtype, const BatchItem* items, int n, int mode, const char* what, hipStream_t s) {
+    const int eb = w_dtype == NNCF_AMD_F32 ? 4 : 2;
+    std::vector<char> done(n, 0);
+    for (int first = 0; first < n; ++first) {
+        if (done[first]) continue;
+        const RowClass c = row_class(items[first].cols * eb / 16);
+        BatchArgs b = {};
+        b.mode = mode;
+        int j = 0;
+        uint32_t acc = 0;
+        auto flush = [&]() -> int {
+            if (j == 0) return NNCF_AMD_OK;
+            b.n = j;
+            hipError_t e;
+            switch (w_dtype) {
+                case NNCF_AMD_F32: e = dispatch_rows<Policy, NNCF_AMD_F32, PACKED>(c, b, s); break;
+                case NNCF_AMD_F16: e = dispatch_rows<Policy, NNCF_AMD_F16, PACKED>(c, b, s); break;
+                case NNCF_AMD_BF16: e = dispatch_rows<Policy, NNCF_AMD_BF16, PACKED>(c, b, s); break;
+                default:
+                    set_error("%s: unsupported weight dtype %d", what, w_dtype);
+                    return NNCF_AMD_ERR_DTYPE;
+            }
+            if (e != hipSuccess) {
+                set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+                return NNCF_AMD_ERR_LAUNCH;
+            }
+            j = 0;
+            acc = 0;
+            b = BatchArgs{};
+            b.mode = mode;
+            return launch_status(what);
+        };
+        for (int k = first; k < n; ++k) {
+            if (done[k]) continue;
+            const RowClass ck = row_class(items[k].cols * eb / 16);
+            if (ck.team != c.team || ck.keep != c.keep) continue;
+            if (j == kMaxBatch || (int64_t)acc + items[k].rows > ((int64_t)1 << 30)) {
+                int st = flush();
+                if (st != NNCF_AMD_OK) return st;
+            }
+            b.tile_start[j] = acc;
+            b.nfull[j] = (uint32_t)(items[k].cols * eb / 16);
+            b.w[j] = items[k].w;
+            b.packed[j] = items[k].packed;
+            b.scale[j] = items[k].scale;
+            b.aux[j] = items[k].aux;
+            acc += (uint32_t)items[k].rows;
+            b.tile_start[j + 1] = acc;
+            ++j;
+            done[k] = 1;
+        }
+        int st = flush();
+        if (st != NNCF_AMD_OK) return st;
+    }
+    return NNCF_AMD_OK;
+}
+
+}  // namespace wc
