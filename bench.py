@@ -208,11 +208,17 @@ def main():
         total_in_bytes = job.in_bytes * world
         value = total_in_bytes / (elapsed / args.steps) / 1e9
         achieved = job.alg_bytes / (dev_ms_per_step * 1e-3) / 1e9
-        batched = not mode.startswith("int8")  # 4-bit modes: multi-tensor launches of <= 48 tensors
-        launches = -(-job.n // 48) if batched else job.n
-        kernel = ("wc::k_grouped_batch<%s, bf16, VPG=%d>" % ("IntPolicy" if job.is_int else "FloatPolicy",
-                                                              (gs if gs != -1 else 0) * 2 // 16)
-                  if batched else "wc::k_row<IntPolicy, bf16>")
+        if gs != -1:  # grouped modes: multi-tensor tile kernel, launches of <= 48 tensors
+            launches = -(-job.n // 48)
+            kernel = "wc::k_grouped_batch<%s, bf16, VPG=%d>" % (
+                {"int4_sym": "IntPolicyT<INT4_SYM>", "int4_asym": "IntPolicyT<INT4_ASYM>", "nf4": "FloatPolicy<NF4>",
+                 "mxfp4": "FloatPolicy<E2M1, MXFP4>"}.get(mode, mode), gs * 2 // 16)
+        else:  # per-channel: multi-tensor row kernel, one series of launches per row-length class
+            per_class = {}
+            for w in job.weights:
+                per_class[w.shape[1]] = per_class.get(w.shape[1], 0) + 1
+            launches = sum(-(-c // 48) for c in per_class.values())
+            kernel = "wc::k_rows_batch<IntPolicyT<%s>, bf16> (%d row-length classes)" % (mode.upper(), len(per_class))
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json), same command
             with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
