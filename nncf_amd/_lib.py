@@ -9,7 +9,7 @@ import torch  # noqa: F401  -- must be imported first so that the library binds 
 from nncf_amd import errors
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnncf_amd_wc.so")
+LIB_PATH = os.environ.get("NNCF_AMD_LIB") or os.path.join(_HERE, "libnncf_amd_wc.so")  # override: developer builds
 
 F32, F16, BF16 = 0, 1, 2
 ZP_NONE, ZP_I32, ZP_F32 = 0, 1, 2

@@ -27,6 +27,49 @@ __global__ __launch_bounds__(256) void k_scale_matrix(float* h, int64_t n, float
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) h[i] = beta == 0.0f ? 0.0f : h[i] * beta;
 }
 
+// Block -> (token split, tile pair).  Blocks go round-robin over the 8 XCDs, each with an L2 of its own, and the
+// kernels are fed from L2 / Infinity Cache (a 256x256 tile needs 1 KiB of X per 131 kflop).  So the blocks that
+// run together on one XCD should share column panels of X: XCD x takes the x-th contiguous eighth of a list in which
+// the upper-triangular tile pairs are ordered band by band (4 tile rows), inside a band in column blocks of 8 --
+// 32 concurrent blocks then read ~12 panels instead of ~40.
+struct PairId {
+    int ti, tj, split;
+};
+__device__ __forceinline__ PairId decode_block(int ntile) {
+    const uint32_t pairs = gridDim.x, total = gridDim.x * gridDim.y;
+    const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t xcd = lin & 7, n = lin >> 3;
+    const uint32_t logical = xcd * (total >> 3) + (xcd < (total & 7) ? xcd : (total & 7)) + n;
+    PairId id;
+    id.split = (int)(logical / pairs);
+    int q = (int)(logical % pairs);
+    // band of 4 tile rows
+    int r0 = 0;
+    for (;;) {
+        const int rows = ntile - r0 < 4 ? ntile - r0 : 4;
+        int in_band = 0;
+        for (int r = 0; r < rows; ++r) in_band += ntile - (r0 + r);
+        if (q < in_band) break;
+        q -= in_band;
+        r0 += 4;
+    }
+    const int rows = ntile - r0 < 4 ? ntile - r0 : 4;
+    // column block of 8 inside the band (columns start at r0; row r holds columns >= r only)
+    for (int c0 = r0;; c0 += 8) {
+        const int c1 = c0 + 8 < ntile ? c0 + 8 : ntile;
+        for (int r = r0; r < r0 + rows; ++r) {
+            const int lo = c0 > r ? c0 : r;
+            const int cnt = c1 - lo > 0 ? c1 - lo : 0;
+            if (q < cnt) {
+                id.ti = r;
+                id.tj = lo + q;
+                return id;
+            }
+            q -= cnt;
+        }
+    }
+}
+
 // stages X[t0 .. t0+HK) x [c0 .. c0+HB) into registers as floats (zero outside the matrix)
 template <int DT, bool VEC>
 struct TileLoader {
@@ -73,15 +116,10 @@ __global__ __launch_bounds__(256) void k_syrk(float* __restrict__ h, const void*
                                               float alpha, int ntile, int64_t rows_per_split) {
     __shared__ __attribute__((aligned(16))) float sa[2][HK][HB];
     __shared__ __attribute__((aligned(16))) float sb[2][HK][HB];
-    // decode the upper-triangular pair index
-    int p = blockIdx.x, ti = 0;
-    while (p >= ntile - ti) {
-        p -= ntile - ti;
-        ++ti;
-    }
-    const int tj = ti + p;
+    const PairId id = decode_block(ntile);
+    const int ti = id.ti, tj = id.tj;
     const int64_t i0 = (int64_t)ti * HB, j0 = (int64_t)tj * HB;
-    const int64_t t_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t t_begin = (int64_t)id.split * rows_per_split;
     const int64_t t_end = t_begin + rows_per_split < T ? t_begin + rows_per_split : T;
     if (t_begin >= t_end) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -143,6 +181,326 @@ __global__ __launch_bounds__(256) void k_syrk(float* __restrict__ h, const void*
             }
 }
 
+// ------------------------------------------------------------------------------------------------ 16-bit inputs
+// bf16 / f16 activations: the products of two 16-bit floats are exact in fp32, so the 16-bit MFMA
+// (v_mfma_f32_32x32x16_{bf16,f16}: 16x the rate of the fp32 one) gives the same sums as the reference's fp32
+// matmul up to the order of the additions.  X stays token-major in LDS exactly as it is in memory ([token][col],
+// 16-byte copies, row pitch 320 B so that four token rows fall on disjoint banks); the transpose the MFMA operand
+// layout needs (a lane holds 8 consecutive k = tokens of one column) is done by the LDS read itself:
+// ds_read_b64_tr_b16 hands lane L of a 16-lane group column L of a 4(token) x 16(col) tile when input lane
+// q + 4m supplies the address of (token m, columns 4q..4q+3) -- semantics probed by tools/trprobe.hip.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HK16 = 32;                 // tokens per stage (two MFMA k-steps)
+constexpr int HP16 = (HB * 2 + 64) / 2;  // row pitch in 16-bit elements
+
+template <int DT>
+__device__ __forceinline__ f32x16 mfma16(const s16x4& lo, const s16x4& hi, const f32x16& c) {
+    struct Pair {
+        s16x4 a, b;
+    } p = {lo, hi};
+    if constexpr (DT == NNCF_AMD_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, p), __builtin_bit_cast(bf16x8, p), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, p), __builtin_bit_cast(f16x8, p), c, 0, 0, 0);
+}
+template <int DT>
+__device__ __forceinline__ f32x16 mfma16(const s16x4& alo, const s16x4& ahi, const s16x4& blo, const s16x4& bhi,
+                                         const f32x16& c) {
+    struct Pair {
+        s16x4 a, b;
+    } pa = {alo, ahi}, pb = {blo, bhi};
+    if constexpr (DT == NNCF_AMD_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pa), __builtin_bit_cast(f16x8, pb), c, 0, 0, 0);
+}
+
+// raw 16-byte vectors of X[t0 .. t0+HK16) x [c0 .. c0+HB) (zero outside the matrix); K % 8 == 0, x 16-byte aligned
+struct RawTile {
+    Vec16 v[2];
+    __device__ __forceinline__ void load(const void* x, int64_t t0, int64_t t_end, int64_t c0, int64_t K) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = threadIdx.x + u * 256;
+            const int row = idx >> 4, cv = idx & 15;
+            const int64_t t = t0 + row, c = c0 + cv * 8;
+            // branch-free: clamped address, then zero what lies outside (no control flow between the loads)
+            const bool ok = t < t_end && c < K;
+            const int64_t tc = t < t_end ? t : t_end - 1, cc = c < K ? c : K - 8;
+            v[u] = *(const Vec16*)((const char*)x + (tc * K + cc) * 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[u].w[q] = ok ? v[u].w[q] : 0u;
+        }
+    }
+    __device__ __forceinline__ void store(uint16_t* lds) const {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = threadIdx.x + u * 256;
+            const int row = idx >> 4, cv = idx & 15;
+            *(Vec16*)(lds + row * HP16 + cv * 8) = v[u];
+        }
+    }
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_syrk16(float* __restrict__ h, const void* __restrict__ x, int64_t T, int64_t K,
+                                                float alpha, int ntile, int64_t rows_per_split) {
+    __shared__ __attribute__((aligned(16))) uint16_t sa[2][HK16 * HP16];
+    __shared__ __attribute__((aligned(16))) uint16_t sb[2][HK16 * HP16];
+    const PairId id = decode_block(ntile);
+    const int ti = id.ti, tj = id.tj;
+    const bool diag = ti == tj;
+    const int64_t i0 = (int64_t)ti * HB, j0 = (int64_t)tj * HB;
+    const int64_t t_begin = (int64_t)id.split * rows_per_split;
+    const int64_t t_end = t_begin + rows_per_split < T ? t_begin + rows_per_split : T;
+    if (t_begin >= t_end) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    RawTile la, lb;
+    la.load(x, t_begin, t_end, i0, K);
+    if (!diag) lb.load(x, t_begin, t_end, j0, K);
+    la.store(sa[0]);
+    if (!diag) lb.store(sb[0]);
+    __syncthreads();
+    int buf = 0;
+    // transposing read: this lane's address inside a k-step tile (see the header comment)
+    const int kh = lane >> 5, grp = (lane >> 4) & 1, i16 = lane & 15;
+    const int lane_off = (8 * kh + (i16 >> 2)) * HP16 + grp * 16 + 4 * (i16 & 3);
+    for (int64_t t0 = t_begin; t0 < t_end; t0 += HK16) {
+        const bool more = t0 + HK16 < t_end;
+        if (more) {
+            la.load(x, t0 + HK16, t_end, i0, K);
+            if (!diag) lb.load(x, t0 + HK16, t_end, j0, K);
+        }
+        const uint16_t* pa = sa[buf] + lane_off;
+        const uint16_t* pb = (diag ? sa[buf] : sb[buf]) + lane_off;
+#pragma unroll
+        for (int ks = 0; ks < HK16 / 16; ++ks) {
+            s16x4 a[2][2], b[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    a[m][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(pa + (16 * ks + 4 * half) * HP16 + wi * 64 + m * 32));
+                    b[m][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(pb + (16 * ks + 4 * half) * HP16 + wj * 64 + m * 32));
+                }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = mfma16<DT>(a[m][0], a[m][1], b[n][0], b[n][1], acc[m][n]);
+        }
+        if (more) {
+            la.store(sa[buf ^ 1]);
+            if (!diag) lb.store(sb[buf ^ 1]);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int kl = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gi = i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                const int64_t gj = j0 + wj * 64 + n * 32 + cl;
+                if (gi < K && gj < K) {
+                    const float val = alpha * acc[m][n][r];
+                    atomicAdd(&h[gi * K + gj], val);
+                    if (!diag) atomicAdd(&h[gj * K + gi], val);
+                }
+            }
+}
+
+// Large-K version: block = 256x256 of H, 4 waves in 2x2, each wave 128x128 = 4x4 MFMA tiles (256 accumulator
+// registers, one wave per SIMD).  Per 16-token k-step a wave issues 16 transposing LDS reads for 16 MFMAs, so the
+// LDS port is busy half of the MFMA time (the 64x64-per-wave kernel above needs it all the time), and a block
+// needs 1 KiB of X per 131 kflop (128 flop/B: what the L2 / Infinity Cache can feed at ~1 PFLOP/s).
+// X goes global -> LDS by buffer DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write; rows past
+// the end of X read as zero through the buffer bounds check; columns past K only feed H entries that are never
+// written), 4 stages of 32 tokens in flight/in use (4 x 32 KiB of LDS, three stages of lookahead).
+// LDS image of a stage and operand: [32 tokens][512 B]; the 16-byte chunk c of token row t sits at chunk position
+// c ^ ((t & 3) << 2), so that the four token rows one transposing read touches fall on disjoint banks; the DMA
+// writes LDS linearly, hence the permutation is applied to its global source addresses.
+constexpr int GB = 256;     // tile edge
+constexpr int GK = 32;      // tokens per stage
+constexpr int GST = 4;      // stages (LDS buffers)
+constexpr int GROW = 512;   // bytes per token row in LDS
+
+// buffer -> LDS DMA of 16 bytes per lane, written out: through the builtin the compiler sees an LDS store of
+// unknown address and puts s_waitcnt vmcnt(0) in front of every later LDS read, which would serialise the pipeline
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buffer_dma16(const i32x4& rsrc, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+                 : "memory", "m0");
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const void* __restrict__ x, int64_t T, int64_t K,
+                                                 float alpha, int ntile, int64_t rows_per_split) {
+    extern __shared__ __attribute__((aligned(1024))) char smem16[];  // [GST][A, B][GK * GROW]
+    const PairId id = decode_block(ntile);
+    const int ti = id.ti, tj = id.tj;
+    const bool diag = ti == tj;
+    const int64_t i0 = (int64_t)ti * GB, j0 = (int64_t)tj * GB;
+    const int64_t t_begin = (int64_t)id.split * rows_per_split;
+    const int64_t t_end = t_begin + rows_per_split < T ? t_begin + rows_per_split : T;
+    if (t_begin >= t_end) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    // this split's rows as a buffer: offsets >= num_records (tokens >= T) read as zero
+    const char* split_base = (const char*)x + t_begin * K * 2;
+    const uint32_t num_records = (uint32_t)((T - t_begin) * K * 2 < 0xffffffffll ? (T - t_begin) * K * 2 : 0xffffffffll);
+    i32x4 rsrc;
+    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)split_base);
+    rsrc[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(((uintptr_t)split_base >> 32) & 0xffffu));  // stride 0
+    rsrc[2] = __builtin_amdgcn_readfirstlane((int)num_records);
+    rsrc[3] = 0x00020000;
+    // DMA: wave w brings token rows 8w .. 8w+7 of a stage, two rows per instruction
+    uint32_t voff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t row = 8 * wave + 2 * u + (lane >> 5);
+        voff[u] = row * (uint32_t)K * 2u + (uint32_t)((lane & 31) ^ ((row & 3) << 2)) * 16u;
+    }
+    const int nst = (int)((t_end - t_begin + GK - 1) / GK);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem16;
+    auto issue = [&](int st) {
+        const uint32_t dst = lds_base + (uint32_t)((st % GST) * (2 * GK * GROW) + 8 * wave * GROW);
+        const uint32_t so = (uint32_t)st * GK * (uint32_t)K * 2u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) buffer_dma16(rsrc, voff[u], so + (uint32_t)i0 * 2u, dst + u * 2 * GROW);
+        if (!diag) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) buffer_dma16(rsrc, voff[u], so + (uint32_t)j0 * 2u, dst + GK * GROW + u * 2 * GROW);
+        }
+    };
+    // transposing reads: per-lane byte offsets inside a stage image for the 4 m-tiles of this wave's A and B panels
+    const int kh = lane >> 5, grp = (lane >> 4) & 1, i16 = lane & 15, r3 = i16 >> 2;
+    const uint32_t lane_const = (uint32_t)(8 * kh + r3) * GROW + (uint32_t)(grp * 2 + ((i16 & 3) >> 1)) * 16u + (uint32_t)(i16 & 1) * 8u;
+    uint32_t offa[4], offb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        offa[m] = lane_const + (uint32_t)(wi * 16 + ((m ^ r3) << 2)) * 16u;
+        offb[m] = lane_const + (uint32_t)(wj * 16 + ((m ^ r3) << 2)) * 16u + (diag ? 0u : (uint32_t)(GK * GROW));
+    }
+    // The MFMA operands of the k-step after the current one are always on their way (register double buffer), also
+    // across the stage boundary: the wait + barrier + DMA issue for the next stage sit between the two k-steps of
+    // a stage, so that one wave per SIMD never waits for an LDS round trip with an idle matrix pipe.
+    auto stage_ready = [&](int st) {  // stage st has landed for everybody; buffer (st - 1) % GST may be overwritten
+        const int later = nst - 1 - st < GST - 2 ? nst - 1 - st : GST - 2;  // later stages whose DMAs may be outstanding
+        if (diag) {  // a diagonal block issues 4 DMAs per stage, the others 8
+            if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (st + GST - 1 < nst) issue(st + GST - 1);
+    };
+    auto read_ops = [&](int st, int ks, s16x4 (*a)[2], s16x4 (*b)[2]) {
+        const char* img = smem16 + (st % GST) * (2 * GK * GROW);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                a[m][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(img + offa[m] + (16 * ks + 4 * half) * GROW));
+                b[m][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(img + offb[m] + (16 * ks + 4 * half) * GROW));
+            }
+    };
+    auto mma = [&](s16x4 (*a)[2], s16x4 (*b)[2]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = mfma16<DT>(a[m][0], a[m][1], b[n][0], b[n][1], acc[m][n]);
+    };
+    static_assert(GK == 32, "two k-steps per stage");
+    for (int st = 0; st < GST - 1 && st < nst; ++st) issue(st);
+    s16x4 a0[4][2], b0[4][2], a1[4][2], b1[4][2];
+    stage_ready(0);
+    read_ops(0, 0, a0, b0);
+    for (int st = 0; st < nst; ++st) {
+        read_ops(st, 1, a1, b1);
+        mma(a0, b0);
+        if (st + 1 < nst) {
+            stage_ready(st + 1);
+            read_ops(st + 1, 0, a0, b0);
+        }
+        mma(a1, b1);
+    }
+    // epilogue with 32-bit offsets (K < 46341 on this path: K*K fits; checked by the host)
+    const uint32_t kl = lane >> 5, cl = lane & 31, Ku = (uint32_t)K;
+    const uint32_t bi = (uint32_t)i0 + wi * 128 + 4 * kl, bj = (uint32_t)j0 + wj * 128 + cl;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            __builtin_amdgcn_sched_barrier(0);  // one accumulator tile at a time: no 256-register read-out
+            const uint32_t gj = bj + n * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t gi = bi + m * 32 + (r & 3) + 8 * (r >> 2);
+                if (gi <= gj && gj < Ku) {
+                    const float val = alpha * acc[m][n][r];
+                    atomicAdd(h + (gi * Ku + gj), val);  // upper triangle only: k_mirror_upper fills in the rest
+                }
+            }
+        }
+}
+
+// H[j][i] = H[i][j] for i < j: the 256x256 kernel accumulates the upper triangle only, so H comes out exactly
+// symmetric whatever the order of the atomic partial sums.  64x64 tiles transposed through LDS: reads and writes
+// are row-contiguous.
+__global__ __launch_bounds__(256) void k_mirror_upper(float* __restrict__ h, uint32_t K) {
+    __shared__ float t[64][65];
+    const uint32_t nt = (K + 63) / 64;
+    uint32_t p = blockIdx.x, bi = 0;  // (bi <= bj) from blockIdx.x
+    while (p >= nt - bi) {
+        p -= nt - bi;
+        ++bi;
+    }
+    const uint32_t bj = bi + p;
+    const uint32_t i0 = bi * 64, j0 = bj * 64;
+    const uint32_t c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+    for (uint32_t r = r4; r < 64; r += 4) {
+        const uint32_t gi = i0 + r, gj = j0 + c;
+        t[r][c] = (gi < K && gj < K) ? h[(size_t)gi * K + gj] : 0.0f;
+    }
+    __syncthreads();
+    for (uint32_t r = r4; r < 64; r += 4) {
+        const uint32_t row = j0 + r, col = i0 + c;  // element (row, col) of the lower triangle <- (col, row)
+        if (row < K && col < row) h[(size_t)row * K + col] = t[c][r];
+    }
+}
+
 }  // namespace wc
 
 extern "C" int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k, float alpha,
@@ -175,6 +533,45 @@ extern "C" int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype,
     dim3 grid((unsigned)pairs, (unsigned)splits);
     const int ev = x_dtype == NNCF_AMD_F32 ? 4 : 8;
     const bool vec = (((uintptr_t)x & 15u) == 0) && (k % ev == 0);
+    if (vec && x_dtype != NNCF_AMD_F32) {  // 16-bit MFMA path
+        const bool big = k >= 2048 && k < 46341;  // 256x256 tiles once there are enough of them (32-bit H offsets)
+        const int tile = big ? GB : HB, kstep = big ? GK : HK16;
+        const int nt = (int)((k + tile - 1) / tile);
+        const int64_t prs = (int64_t)nt * (nt + 1) / 2;
+        const int64_t want = big ? 2048 : 768;  // big: one block per CU at a time -> >= 8 rounds keep the tail short
+        int64_t sp = prs >= want ? 1 : (want + prs - 1) / prs;
+        const int64_t maxsp = (tokens + (big ? 32 : 8) * kstep - 1) / ((big ? 32 : 8) * kstep);  // >= 1024 / 256 tokens per block
+        if (sp > maxsp) sp = maxsp;
+        if (sp > 65535) sp = 65535;
+        int64_t rps = (tokens + sp - 1) / sp;
+        rps = (rps + kstep - 1) / kstep * kstep;
+        sp = (tokens + rps - 1) / rps;
+        dim3 g16((unsigned)prs, (unsigned)sp);
+        if (big) {
+            constexpr size_t lds_bytes = (size_t)GST * 2 * GK * GROW;  // 131072
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                    return launch_status("hessian_syrk16b attribute");
+                attr_set = true;
+            }
+            if (x_dtype == NNCF_AMD_BF16)
+                hipLaunchKernelGGL((k_syrk16b<NNCF_AMD_BF16>), g16, dim3(256), lds_bytes, s, h, x, tokens, k, alpha, nt, rps);
+            else
+                hipLaunchKernelGGL((k_syrk16b<NNCF_AMD_F16>), g16, dim3(256), lds_bytes, s, h, x, tokens, k, alpha, nt, rps);
+            int st16 = launch_status("hessian_syrk16b");
+            if (st16 != NNCF_AMD_OK) return st16;
+            const uint32_t mt = (uint32_t)((k + 63) / 64);
+            hipLaunchKernelGGL(k_mirror_upper, dim3(mt * (mt + 1) / 2), dim3(256), 0, s, h, (uint32_t)k);
+            return launch_status("hessian_mirror");
+        }
+        if (x_dtype == NNCF_AMD_BF16)
+            hipLaunchKernelGGL((k_syrk16<NNCF_AMD_BF16>), g16, dim3(256), 0, s, h, x, tokens, k, alpha, nt, rps);
+        else
+            hipLaunchKernelGGL((k_syrk16<NNCF_AMD_F16>), g16, dim3(256), 0, s, h, x, tokens, k, alpha, nt, rps);
+        return launch_status("hessian_syrk16");
+    }
 #define LAUNCH(DT)                                                                                                      \
     if (vec)                                                                                                            \
         hipLaunchKernelGGL((k_syrk<DT, true>), grid, dim3(256), 0, s, h, x, tokens, k, alpha, ntile, rows_per_split);   \

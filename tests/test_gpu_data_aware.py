@@ -59,7 +59,7 @@ def test_golden_hessian(golden):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("T,K", [(300, 256), (37, 100), (1000, 384), (64, 4096)])
+@pytest.mark.parametrize("T,K", [(300, 256), (37, 100), (1000, 384), (64, 4096), (700, 2312), (33, 2048), (4500, 2560)])
 def test_hessian_vs_float64(T, K, dtype):
     from nncf_amd import gptq
     rng = np.random.default_rng(T + K)
