@@ -1,11 +1,13 @@
 // wc_gptq.hip -- GPTQ in-block column sweep for gfx950 (gptq.py:298-361, one block of <= 128 columns).
 //
 // Rows of the weight are independent in GPTQ: the quantization error of W[r, c] only propagates along row r
-// (W[r, c:] -= err * Hinv[c, c:]).  One lane owns one row: its slice of the current block lives in LDS,
-// column-major [128][64] so that the 64 lanes of the wave touch 64 consecutive floats (conflict free); the
-// Hinv row is wave-uniform and comes through the scalar cache.  The ~K sequential Python iterations x ~10 kernel
-// launches of the reference become K/128 launches; the trailing update W[:, i2:] -= Err @ Hinv[i1:i2, i2:]
-// (gptq.py:363) stays a plain GEMM at the caller.
+// (W[r, c:] -= err * Hinv[c, c:]).  Sixteen lanes own one row: column j of the block lives in register j / 16 of
+// lane j % 16 (interleaved, so that every lane has columns left to update until the end of the sweep).  Per
+// column: the owner's value is broadcast over the 16 lanes (ds_bpermute), every lane quantizes it (same parameters,
+// no divergence) and updates its own remaining columns with the Hinv row from LDS (the 128x128 Hinv block is staged
+// once per workgroup of 16 rows).  Loads and stores of W, Q and Err are coalesced along the row.  The ~K
+// sequential Python iterations x ~10 kernel launches of the reference become K/128 launches; the trailing update
+// W[:, i2:] -= Err @ Hinv[i1:i2, i2:] (gptq.py:363) stays a plain GEMM at the caller.
 //
 // Numerics follow the reference step by step: group parameters are computed from `weight` (the tensor WITHOUT
 // this block's in-block updates, gptq.py:315-333) with the same policy arithmetic as the lowering kernels, the
@@ -16,17 +18,23 @@
 
 namespace wc {
 
-constexpr int GB = 128;  // max columns per call
-constexpr int GR = 64;   // rows per workgroup (one wave)
+constexpr int GB = 128;   // max columns per call
+constexpr int GLPR = 16;  // lanes per row
+constexpr int GRPB = 16;  // rows per workgroup (256 threads)
+constexpr int GCPL = GB / GLPR;  // columns per lane
 
 template <typename Policy>
-__global__ __launch_bounds__(GR) void k_gptq_block(const float* __restrict__ weight, float* __restrict__ quantized,
-                                                   float* __restrict__ err_block, const float* __restrict__ hinv,
-                                                   int64_t rows, int64_t K, int64_t i1, int count, int64_t gs, int mode,
-                                                   float* scales, int32_t* zps, int given) {
-    __shared__ float wb[GB][GR];
+__global__ __launch_bounds__(256) void k_gptq_block(const float* __restrict__ weight, float* __restrict__ quantized,
+                                                    float* __restrict__ err_block, const float* __restrict__ hinv,
+                                                    int64_t rows, int64_t K, int64_t i1, int count, int64_t gs, int mode,
+                                                    float* scales, int32_t* zps, int given) {
+    extern __shared__ float hb[];  // [GB][GB]: Hinv[i1 + i][i1 + j], zero outside the block
     __shared__ float lds[kPolicyLds];
     Policy::init_shared(lds);
+    for (int idx = threadIdx.x; idx < GB * GB; idx += 256) {
+        const int i = idx / GB, j = idx % GB;
+        hb[idx] = (i < count && j < count) ? hinv[(i1 + i) * K + i1 + j] : 0.0f;
+    }
     __syncthreads();
     GroupArgs a = {};
     a.mode = mode;
@@ -36,39 +44,71 @@ __global__ __launch_bounds__(GR) void k_gptq_block(const float* __restrict__ wei
     a.scale_out = scales;
     a.zp_out = zps;
     const Policy pol(a, lds);
-    const int tid = threadIdx.x;
-    const int64_t r = (int64_t)blockIdx.x * GR + tid;
-    if (r >= rows) return;  // no block-wide synchronisation below
+    const int tid = threadIdx.x, l = tid % GLPR, lane = tid & 63;
+    const int64_t row = (int64_t)blockIdx.x * GRPB + tid / GLPR;
+    const bool active = row < rows;
+    const int64_t r = active ? row : rows - 1;  // idle lanes shadow the last row (they take part in the shuffles)
     const int64_t ngroups = K / gs;
     const float* wrow = weight + r * K;
-    for (int j = 0; j < count; ++j) wb[j][tid] = wrow[i1 + j];
+    float w[GCPL], qv[GCPL], ev[GCPL];
+#pragma unroll
+    for (int k = 0; k < GCPL; ++k) {
+        const int j = k * GLPR + l;
+        w[k] = j < count ? wrow[i1 + j] : 0.0f;
+        qv[k] = 0.0f;
+        ev[k] = 0.0f;
+    }
     typename Policy::Par par;
     if (i1 % gs != 0) par = pol.load(a, r * ngroups + i1 / gs);  // the group began in an earlier block
-    for (int i = 0; i < count; ++i) {
-        const int64_t c = i1 + i;
-        if (c % gs == 0) {
-            if (given) {  // parameters supplied by the caller (scale estimation inside GPTQ, gptq.py:319-327)
-                par = pol.load(a, r * ngroups + c / gs);
-            } else {
-                typename Policy::Stat st = pol.stat_init();
-                for (int64_t k = 0; k < gs; ++k) pol.stat_add(st, wrow[c + k]);
-                par = pol.compute(st);
-                pol.template store<false>(a, r * ngroups + c / gs, par);
+#pragma unroll
+    for (int k0 = 0; k0 < GCPL; ++k0) {
+        for (int lo = 0; lo < GLPR; ++lo) {
+            const int i = k0 * GLPR + lo;
+            if (i >= count) break;
+            const int64_t c = i1 + i;
+            if (c % gs == 0) {
+                if (given) {  // parameters supplied by the caller (scale estimation inside GPTQ, gptq.py:319-327)
+                    par = pol.load(a, r * ngroups + c / gs);
+                } else {
+                    typename Policy::Stat st = pol.stat_init();
+                    for (int64_t k = l; k < gs; k += GLPR) pol.stat_add(st, wrow[c + k]);
+                    pol.template stat_lanes<GLPR>(st);
+                    par = pol.compute(st);
+                    if (active && l == 0) pol.template store<false>(a, r * ngroups + c / gs, par);
+                }
+            }
+            // the owner (lane lo of the row) broadcasts column i
+            const float wv = __builtin_bit_cast(
+                float, __builtin_amdgcn_ds_bpermute(((lane & ~(GLPR - 1)) + lo) * 4, __builtin_bit_cast(int, w[k0])));
+            int code;
+            float val;
+            pol.quant(wv, par, code, val);
+            const float q = pol.dq(code, val, par);
+            const float* hrow = hb + i * GB;
+            const float err = (wv - q) / hrow[i];
+            if (l == lo) {
+                qv[k0] = q;
+                ev[k0] = err;
+            }
+            {
+                const float prod = err * hrow[k0 * GLPR + l];
+                w[k0] = l >= lo ? w[k0] - prod : w[k0];
+            }
+#pragma unroll
+            for (int k = k0 + 1; k < GCPL; ++k) {
+                const float prod = err * hrow[k * GLPR + l];
+                w[k] = w[k] - prod;
             }
         }
-        const float w = wb[i][tid];
-        int code;
-        float val;
-        pol.quant(w, par, code, val);
-        const float q = pol.dq(code, val, par);
-        quantized[r * K + c] = q;
-        const float* hrow = hinv + c * K + i1;  // wave-uniform
-        const float err = (w - q) / hrow[i];
-        for (int j = i; j < count; ++j) {
-            const float prod = err * hrow[j];
-            wb[j][tid] = wb[j][tid] - prod;
+    }
+    if (!active) return;
+#pragma unroll
+    for (int k = 0; k < GCPL; ++k) {
+        const int j = k * GLPR + l;
+        if (j < count) {
+            quantized[r * K + i1 + j] = qv[k];
+            err_block[r * count + j] = ev[k];
         }
-        err_block[r * count + i] = err;
     }
 }
 
@@ -96,15 +136,24 @@ extern "C" int nncf_amd_gptq_block(const float* weight, float* quantized, float*
     }
     if (!asym) zps = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((rows + GR - 1) / GR));
+    const dim3 grid((unsigned)((rows + GRPB - 1) / GRPB));
+    constexpr size_t hb_bytes = (size_t)GB * GB * sizeof(float);  // 64 KiB of dynamic LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_gptq_block<IntPolicy>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_gptq_block<FloatPolicy<true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_gptq_block<FloatPolicy<false>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess)
+            return launch_status("gptq_block attribute");
+        attr_set = true;
+    }
     if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
-        hipLaunchKernelGGL((k_gptq_block<IntPolicy>), grid, dim3(GR), 0, s, weight, quantized, err_block, hinv, rows, k, i1,
+        hipLaunchKernelGGL((k_gptq_block<IntPolicy>), grid, dim3(256), hb_bytes, s, weight, quantized, err_block, hinv, rows, k, i1,
                            (int)count, gs, mode, scales, zps, use_given_params);
     } else if (mode == NNCF_AMD_NF4) {
-        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<true>>), grid, dim3(GR), 0, s, weight, quantized, err_block, hinv, rows,
+        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<true>>), grid, dim3(256), hb_bytes, s, weight, quantized, err_block, hinv, rows,
                            k, i1, (int)count, gs, mode, scales, zps, use_given_params);
     } else if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) {
-        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<false>>), grid, dim3(GR), 0, s, weight, quantized, err_block, hinv, rows,
+        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<false>>), grid, dim3(256), hb_bytes, s, weight, quantized, err_block, hinv, rows,
                            k, i1, (int)count, gs, mode, scales, zps, use_given_params);
     } else {
         set_error("gptq_block: unsupported mode %d", mode);

@@ -76,9 +76,7 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
     ngroups = K // gs
     damp = damp_percent * torch.mean(torch.diag(hessian))
     hessian[idx, idx] += damp
-    Hc = torch.linalg.cholesky(hessian)
-    Hc = torch.cholesky_inverse(Hc)
-    hinv = torch.linalg.cholesky(Hc, upper=True).contiguous()
+    hinv = _upper_cholesky_of_inverse(hessian)
 
     asym = config.is_integer and config.is_asym_mode
     Q = torch.zeros_like(W)
@@ -117,6 +115,18 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
         if out_zps is not None:
             out_zps = out_zps.squeeze(-1)
     return Q, out_scales, out_zps
+
+
+def _upper_cholesky_of_inverse(hessian: torch.Tensor) -> torch.Tensor:
+    """U upper triangular with H^-1 = U^T U: what the reference gets from cholesky -> cholesky_inverse ->
+    cholesky(upper=True) (gptq.py:283-285), from ONE factorization instead of two plus an inversion.  With J the
+    index reversal, J H J = L L^T (plain Cholesky) gives H = R R^T for the upper triangular R = J L J, hence
+    H^-1 = R^-T R^-1 = U^T U with U = R^-1, and a Cholesky factor with positive diagonal is unique.  In fp32 this is
+    at least as close to the exact U as the three-step chain (one rounding cascade less)."""
+    L = torch.linalg.cholesky(torch.flip(hessian, (0, 1)))
+    R = torch.flip(L, (0, 1))
+    eye = torch.eye(hessian.shape[0], dtype=hessian.dtype, device=hessian.device)
+    return torch.linalg.solve_triangular(R, eye, upper=True).contiguous()
 
 
 class GPTQ:
