@@ -68,30 +68,40 @@ def data_aware_step(weight: torch.Tensor, reduction_axes, config: WeightCompress
         a_min = torch.quantile(gscale, 0.1).to(torch.float32)
         gscale = torch.clip(gscale, min=a_min, max=1e2)
         fp32_out = torch.matmul(gweight, gacts)
-        # the reference compares python-visible scalars each step; keep the running minimum on the device
+        # The reference walks the 100 alphas one by one (awq.py:300-348: ~10 small ops per step).  Here all steps of
+        # a group go through the same arithmetic at once: [steps, N, gs] scaled weights -> ONE quantize-dequantize
+        # launch (rows are independent) -> batched matmul -> per-step mean |diff|; the running "strictly better"
+        # minimum of the reference is the argmin with the earliest index on ties.
         min_diff = torch.max(torch.abs(fp32_out))
-        best_scale = None
-        cur_scales, cur_diffs = [], []
+        alphas = []
         alpha = alpha_min
         for _ in range(steps):
-            cur_scale = gscale ** alpha
-            if prev_s is not None:
-                threshold = FP16_OVERFLOW_MARGIN * FP16_MAX_VALUE
-                mag_base = prev_w[batch_idx, offset:offset + group_size] * prev_s * prev_weight.shape[reduction_axis]
-                magnitudes = mag_base / cur_scale
-                if magnitudes.max() >= threshold:
-                    cur_scale = torch.where(magnitudes < threshold, cur_scale, mag_base / threshold)
-            g_dq = qdq((gweight * cur_scale).contiguous(), awq_config, -1)
-            sacts = gacts / cur_scale.unsqueeze(1)
-            cur_out = torch.matmul(g_dq, sacts)
-            cur_diffs.append(torch.mean(torch.abs(cur_out - fp32_out)))
-            cur_scales.append(cur_scale)
+            alphas.append(alpha)
             alpha += alpha_step
-        # first strict improvement chain == argmin with the earliest index on ties (awq.py:346-348), one host sync
-        diffs = torch.stack(cur_diffs)
+        alphas_t = torch.tensor(alphas, dtype=torch.float64, device=gscale.device).to(torch.float32)
+        all_scales = torch.pow(gscale.unsqueeze(0), alphas_t.unsqueeze(1))  # [steps, gs]
+        half = alphas_t == 0.5  # tensor ** python-scalar takes the sqrt path for exactly 0.5
+        if bool(half.any()):
+            all_scales[half] = torch.sqrt(gscale)
+        if prev_s is not None:
+            threshold = FP16_OVERFLOW_MARGIN * FP16_MAX_VALUE
+            mag_base = prev_w[batch_idx, offset:offset + group_size] * prev_s * prev_weight.shape[reduction_axis]
+            magnitudes = mag_base.unsqueeze(0) / all_scales
+            clip_rows = magnitudes.amax(dim=1, keepdim=True) >= threshold
+            all_scales = torch.where(clip_rows & ~(magnitudes < threshold), (mag_base / threshold).unsqueeze(0), all_scales)
+        n_rows, n_tok = gweight.shape[0], gacts.shape[1]
+        chunk = max(1, min(steps, (1 << 28) // max(1, n_rows * max(group_size, n_tok))))  # <= 1 GiB of fp32 per temporary
+        diffs = []
+        for c0 in range(0, steps, chunk):
+            sc = all_scales[c0:c0 + chunk]
+            scaled = (gweight.unsqueeze(0) * sc.unsqueeze(1)).reshape(-1, gweight.shape[1]).contiguous()
+            g_dq = qdq(scaled, awq_config, -1).reshape(sc.shape[0], n_rows, -1)
+            sacts = gacts.unsqueeze(0) / sc.unsqueeze(2)
+            cur_out = torch.bmm(g_dq, sacts)
+            diffs.append(torch.mean(torch.abs(cur_out - fp32_out.unsqueeze(0)), dim=(1, 2)))
+        diffs = torch.cat(diffs)
         best = int(torch.argmin(diffs))
-        if bool(diffs[best] < min_diff):
-            best_scale = cur_scales[best]
+        best_scale = all_scales[best] if bool(diffs[best] < min_diff) else None
         if best_scale is not None:
             scale[batch_idx, offset:offset + group_size] = best_scale
     if is_2d_weight:
