@@ -182,6 +182,18 @@ int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype, int64_t to
                                 float beta, void* stream);
 
 /*
+ * Token mean of a LIST of separately allocated activation samples x_i[tokens_i, hidden] (one calibration item each):
+ * the per-item MeanReducer of the statistics the data-aware algorithms consume (WCTensorStatistic.mean_values,
+ * src/nncf/quantization/algorithms/weight_compression/gptq.py:381-396; MeanReducer collectors.py:512-518), two
+ * launches per 64 samples instead of three per sample.  means_out: fp32 [n, hidden] (cast to the activation dtype
+ * by the caller, as the reducer returns it).  xs_host / tokens_host are HOST arrays of n entries.
+ */
+size_t nncf_amd_token_mean_workspace(int n, int64_t max_tokens, int64_t hidden);
+int nncf_amd_token_mean_batched(int n, const void* const* xs_host, int x_dtype, const int64_t* tokens_host,
+                                int64_t hidden, float* means_out, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
+/*
  * GPTQ in-block column sweep (gptq.py:298-361, one block of `count` <= 128 columns starting at column i1).
  * For every row independently: at group starts (re)compute scale[, zp] from `weight` (the not-in-block-updated
  * tensor, gptq.py:315-333), quantize-dequantize the column, propagate err = (w-q)/Hinv[c,c] to the remaining

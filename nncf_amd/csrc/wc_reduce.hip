@@ -232,6 +232,100 @@ static int run_reduce(const void* x, int64_t batch, int64_t tokens, int64_t hidd
     return launch_status("act_finalize");
 }
 
+// ------------------------------------------------------------------------------------------------ list of samples
+// Token mean of MANY separately allocated activation samples x_i[tokens_i, hidden] in one pair of launches
+// (WCTensorStatistic collection, gptq.py:381-396 / MeanReducer per calibration item: a launch triple per sample
+// caps 16 MB samples at ~0.5 TB/s).  Up to kMaxSamples samples per launch, ragged token counts.
+constexpr int kMaxSamples = 64;
+struct SampleList {
+    const void* x[kMaxSamples];
+    int64_t tokens[kMaxSamples];
+};
+
+// ws[(z * nsplit + s) * hidden + k] = sum over the s-th token slice of sample z
+template <int DT, bool VEC>
+__global__ __launch_bounds__(64) void k_mean_partials(SampleList l, int64_t hidden, int nsplit, float* __restrict__ ws) {
+    constexpr int E = VEC ? Elem<DT>::kPerVec : 1;
+    const int64_t col0 = ((int64_t)blockIdx.x * 64 + threadIdx.x) * E;
+    if (col0 >= hidden) return;
+    const int s = blockIdx.y, z = blockIdx.z;
+    const void* x = l.x[z];
+    const int64_t tokens = l.tokens[z];
+    const int64_t rows_per = (tokens + nsplit - 1) / nsplit;
+    const int64_t t0 = s * rows_per;
+    const int64_t t1 = t0 + rows_per < tokens ? t0 + rows_per : tokens;
+    float acc[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) acc[i] = 0.0f;
+    int64_t t = t0;
+    if constexpr (VEC) {
+        for (; t + 8 <= t1; t += 8) {  // 8 rows in flight per thread
+            Vec16 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = *(const Vec16*)((const char*)x + ((t + u) * hidden + col0) * Elem<DT>::kBytes);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float f[E];
+                unpack<DT>(r[u], f);
+#pragma unroll
+                for (int i = 0; i < E; ++i) acc[i] += f[i];
+            }
+        }
+    }
+    for (; t < t1; ++t) {
+        float f[E];
+        if constexpr (VEC) {
+            unpack<DT>(*(const Vec16*)((const char*)x + (t * hidden + col0) * Elem<DT>::kBytes), f);
+        } else {
+            f[0] = Elem<DT>::load(x, t * hidden + col0);
+        }
+#pragma unroll
+        for (int i = 0; i < E; ++i) acc[i] += f[i];
+    }
+    float* p = ws + ((int64_t)z * nsplit + s) * hidden + col0;
+#pragma unroll
+    for (int i = 0; i < E; ++i) p[i] = acc[i];
+}
+
+__global__ __launch_bounds__(256) void k_mean_merge(SampleList l, int64_t hidden, int nsplit, const float* __restrict__ ws,
+                                                    float* __restrict__ means) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int z = blockIdx.y;
+    if (k >= hidden) return;
+    double acc = 0.0;
+    for (int s = 0; s < nsplit; ++s) acc += (double)ws[((int64_t)z * nsplit + s) * hidden + k];
+    means[(int64_t)z * hidden + k] = (float)(acc / (double)l.tokens[z]);
+}
+
+static inline int mean_nsplit(int n, int64_t max_tokens, int64_t hidden) {
+    const int64_t col_blocks = (hidden + 511) / 512;
+    int64_t want = 8192 / ((int64_t)n * col_blocks);
+    const int64_t max_split = (max_tokens + 63) / 64;
+    if (want > max_split) want = max_split;
+    if (want > 128) want = 128;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+template <int DT>
+static int run_mean_list(const SampleList& l, int n, int64_t max_tokens, int64_t hidden, bool vec, float* means, float* ws,
+                         hipStream_t s) {
+    const int nsplit = mean_nsplit(n, max_tokens, hidden);
+    if (vec) {
+        const int64_t cpb = 64 * Elem<DT>::kPerVec;
+        hipLaunchKernelGGL((k_mean_partials<DT, true>), dim3((unsigned)((hidden + cpb - 1) / cpb), (unsigned)nsplit, (unsigned)n),
+                           dim3(64), 0, s, l, hidden, nsplit, ws);
+    } else {
+        hipLaunchKernelGGL((k_mean_partials<DT, false>), dim3((unsigned)((hidden + 63) / 64), (unsigned)nsplit, (unsigned)n),
+                           dim3(64), 0, s, l, hidden, nsplit, ws);
+    }
+    int st = launch_status("mean_partials");
+    if (st != NNCF_AMD_OK) return st;
+    hipLaunchKernelGGL(k_mean_merge, dim3((unsigned)((hidden + 255) / 256), (unsigned)n), dim3(256), 0, s, l, hidden, nsplit,
+                       (const float*)ws, means);
+    return launch_status("mean_merge");
+}
+
 }  // namespace wc
 
 extern "C" size_t nncf_amd_reduce_workspace(int64_t batch, int64_t tokens, int64_t hidden) {
@@ -268,4 +362,62 @@ extern "C" int nncf_amd_reduce_activation_stats(const void* x, int x_dtype, int6
             set_error("reduce_activation_stats: unsupported dtype %d", x_dtype);
             return NNCF_AMD_ERR_DTYPE;
     }
+}
+
+extern "C" size_t nncf_amd_token_mean_workspace(int n, int64_t max_tokens, int64_t hidden) {
+    if (n <= 0 || max_tokens <= 0 || hidden <= 0) return 0;
+    const int per = n < wc::kMaxSamples ? n : wc::kMaxSamples;
+    return (size_t)per * (size_t)wc::mean_nsplit(per, max_tokens, hidden) * (size_t)hidden * sizeof(float);
+}
+
+extern "C" int nncf_amd_token_mean_batched(int n, const void* const* xs_host, int x_dtype, const int64_t* tokens_host,
+                                           int64_t hidden, float* means_out, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+    using namespace wc;
+    if (n < 0 || hidden <= 0 || (n > 0 && (!xs_host || !tokens_host || !means_out))) {
+        set_error("token_mean_batched: bad argument (n=%d hidden=%lld)", n, (long long)hidden);
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (x_dtype != NNCF_AMD_F32 && x_dtype != NNCF_AMD_F16 && x_dtype != NNCF_AMD_BF16) {
+        set_error("token_mean_batched: unsupported dtype %d", x_dtype);
+        return NNCF_AMD_ERR_DTYPE;
+    }
+    int64_t max_tokens = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!xs_host[i] || tokens_host[i] <= 0) {
+            set_error("token_mean_batched: sample %d is NULL or empty", i);
+            return NNCF_AMD_ERR_BAD_ARG;
+        }
+        max_tokens = tokens_host[i] > max_tokens ? tokens_host[i] : max_tokens;
+    }
+    if (n == 0) return NNCF_AMD_OK;
+    const size_t need = nncf_amd_token_mean_workspace(n, max_tokens, hidden);
+    if (!workspace || workspace_bytes < need) {
+        set_error("token_mean_batched: workspace needs %zu bytes", need);
+        return NNCF_AMD_ERR_WORKSPACE;
+    }
+    const int ev = x_dtype == NNCF_AMD_F32 ? 4 : 8;
+    for (int first = 0; first < n; first += kMaxSamples) {
+        const int cnt = n - first < kMaxSamples ? n - first : kMaxSamples;
+        SampleList l = {};
+        bool vec = hidden % ev == 0;
+        int64_t mt = 0;
+        for (int i = 0; i < cnt; ++i) {
+            l.x[i] = xs_host[first + i];
+            l.tokens[i] = tokens_host[first + i];
+            vec = vec && (((uintptr_t)l.x[i] & 15u) == 0);
+            mt = l.tokens[i] > mt ? l.tokens[i] : mt;
+        }
+        // the workspace was sized for min(n, kMaxSamples) samples of max_tokens tokens: every chunk fits
+        (void)mt;
+        float* out = means_out + (size_t)first * (size_t)hidden;
+        int st;
+        switch (x_dtype) {
+            case NNCF_AMD_F32: st = run_mean_list<NNCF_AMD_F32>(l, cnt, max_tokens, hidden, vec, out, (float*)workspace, (hipStream_t)stream); break;
+            case NNCF_AMD_F16: st = run_mean_list<NNCF_AMD_F16>(l, cnt, max_tokens, hidden, vec, out, (float*)workspace, (hipStream_t)stream); break;
+            default: st = run_mean_list<NNCF_AMD_BF16>(l, cnt, max_tokens, hidden, vec, out, (float*)workspace, (hipStream_t)stream); break;
+        }
+        if (st != NNCF_AMD_OK) return st;
+    }
+    return NNCF_AMD_OK;
 }

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from nncf_amd import _lib
-from nncf_amd.errors import UnsupportedModelError
+from nncf_amd.errors import InternalError, UnsupportedModelError
 
 
 def activation_stats(x: torch.Tensor, want_mean: bool = True, want_stats: bool = True):
@@ -146,11 +146,45 @@ class WCTensorStatistic:
     shape_values: List[Tuple[int, ...]] = field(default_factory=list)
 
 
+def token_means(activations: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """Per-item token mean [hidden] of many activation samples [..., tokens, hidden] (flattened to [T_i, hidden]) in
+    one pair of launches per 64 samples (`nncf_amd_token_mean_batched`); values in the activation dtype, as
+    MeanReducer returns them."""
+    import ctypes
+
+    acts = [a if a.is_contiguous() else a.contiguous() for a in activations]
+    if not acts:
+        return []
+    _lib.require_gpu(acts[0], "token_means")
+    dev, dt, hidden = acts[0].device, acts[0].dtype, acts[0].shape[-1]
+    for a in acts:
+        if a.device != dev or a.dtype != dt or a.shape[-1] != hidden or a.numel() == 0:
+            raise InternalError("token_means: samples of one dtype, device and hidden size expected")
+    n = len(acts)
+    tokens = [a.numel() // hidden for a in acts]
+    lib = _lib.lib()
+    means = torch.empty((n, hidden), dtype=torch.float32, device=dev)
+    nbytes = lib.nncf_amd_token_mean_workspace(n, max(tokens), hidden)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    xs = (ctypes.c_void_p * n)(*[a.data_ptr() for a in acts])
+    tk = (ctypes.c_int64 * n)(*tokens)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nncf_amd_token_mean_batched(n, xs, _lib.dtype_id(acts[0]), tk, hidden, _lib.ptr(means), _lib.ptr(ws),
+                                                   nbytes, _lib.stream_of(acts[0])))
+    means = means.to(dt)
+    return [means[i] for i in range(n)]
+
+
 def activations_to_wc_statistics(activations: Sequence[torch.Tensor]) -> WCTensorStatistic:
     """gptq.py:381-396."""
-    means, shapes = [], []
-    for act in activations:
-        shapes.append(tuple(act.shape))
+    acts = list(activations)
+    shapes = [tuple(a.shape) for a in acts]
+    uniform = len(acts) > 1 and all(a.dtype == acts[0].dtype and a.shape[-1] == acts[0].shape[-1] and a.device == acts[0].device
+                                    for a in acts)
+    if uniform:
+        return WCTensorStatistic(token_means(acts), shapes)
+    means = []
+    for act in acts:
         m, _ = activation_stats(act.reshape(1, -1, act.shape[-1]), want_stats=False)
         means.append(m.to(act.dtype))
     return WCTensorStatistic(means, shapes)

@@ -79,3 +79,24 @@ def test_oracle_shapes(shape, dtype):
     np.testing.assert_allclose(float(stats[3]), np.sum(xr.astype(np.float64) ** 2), rtol=1e-5)
     with pytest.raises(Exception):
         S.MeanReducer(axes=(0,))._reduce_out_of_place([x])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_token_means_of_a_sample_list(dtype):
+    """nncf_amd_token_mean_batched: ragged token counts, > 64 samples (several launches), odd hidden size (scalar
+    path) -- against float64 and against the per-sample reducer."""
+    from nncf_amd import statistics as S
+    rng = np.random.default_rng(5)
+    for hidden, counts in ((512, [1, 7, 300, 2048, 33]), (100, [5, 64, 129]), (256, [40] * 70)):
+        xs32 = [(rng.standard_normal((1, t, hidden)) * 3 + rng.standard_normal(hidden) * 10).astype(np.float32) for t in counts]
+        xs = [to_dev(x, dtype) for x in xs32]
+        got = S.activations_to_wc_statistics(xs)
+        assert got.shape_values == [tuple(x.shape) for x in xs]
+        for x, m in zip(xs, got.mean_values):
+            ref = host(x).astype(np.float64).reshape(-1, hidden).mean(0)
+            one, _ = S.activation_stats(x, want_stats=False)
+            tol = 1e-6 if dtype == "f32" else (8e-3 if dtype == "bf16" else 1e-3)
+            np.testing.assert_allclose(host(m).astype(np.float64), ref, rtol=tol, atol=tol * np.abs(ref).max())
+            assert m.dtype == x.dtype and tuple(m.shape) == (hidden,)
+            np.testing.assert_allclose(host(m).astype(np.float32), host(one.to(x.dtype)).astype(np.float32), rtol=tol,
+                                       atol=tol * np.abs(ref).max())
