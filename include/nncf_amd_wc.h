@@ -182,6 +182,17 @@ int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype, int64_t to
                                 float beta, void* stream);
 
 /*
+ * Fused inner step of scale estimation (ScaleEstimation.calculate_quantization_params,
+ * src/nncf/quantization/algorithms/weight_compression/scale_estimation.py:300-360; get_target_zero_mask :380-393,
+ * estimate_scales :396-409): quantize every group with the candidate `scale` (and `zero_point`, fp32 as scale
+ * estimation carries it; NULL for symmetric / float modes), target = q - zp, zero_mask = zero_scale * isclose(target, 0),
+ *     out[g] = sum_k |w[g,k]| / (|target[g,k]| + zero_mask[g,k]) * importance[g,k]
+ * weight, importance: fp32 [n_groups, group_size] (the grouped view, contiguous); scale, zero_point, out: fp32 [n_groups].
+ */
+int nncf_amd_se_estimate(const float* weight, const float* importance, int64_t n_groups, int64_t group_size, int mode,
+                         const float* scale, const float* zero_point, float zero_scale, float* out, void* stream);
+
+/*
  * Token mean of a LIST of separately allocated activation samples x_i[tokens_i, hidden] (one calibration item each):
  * the per-item MeanReducer of the statistics the data-aware algorithms consume (WCTensorStatistic.mean_values,
  * src/nncf/quantization/algorithms/weight_compression/gptq.py:381-396; MeanReducer collectors.py:512-518), two

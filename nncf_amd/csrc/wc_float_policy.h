@@ -277,6 +277,7 @@ struct FloatPolicy {
     }
     __device__ __forceinline__ float dq(int, float value, const Par& p) const { return value * p.scale; }
     __device__ __forceinline__ int nibble(int code) const { return code; }
+    __device__ __forceinline__ float target(float value, const Par&) const { return value; }
 };
 
 }  // namespace wc

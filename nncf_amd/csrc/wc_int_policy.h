@@ -109,6 +109,8 @@ struct IntPolicyT {
         return p.has_zp ? (value - p.zpf) * p.scale : value * p.scale;
     }
     __device__ __forceinline__ int nibble(int code) const { return code + (m.asym ? 0 : 8); }
+    // scale_estimation.py:380-393: the unscaled tensor minus the zero point
+    __device__ __forceinline__ float target(float value, const Par& p) const { return p.has_zp ? value - p.zpf : value; }
 
     // k[i] <- clip(rne(w/s [+ z])) for N elements sharing one parameter set; exact (see the header comment).
     // f and k may alias: elements are processed in chunks of C whose inputs stay intact until the chunk's

@@ -156,3 +156,35 @@ def test_gptq_sweep_matches_oracle_given_same_hinv(mode, gs):
     assert close.mean() > 0.995, close.mean()
     # first block: no GEMM involved yet -> bit exact
     assert np.array_equal(host(Qd)[:, :bs], Q_ref[:, :bs])
+
+
+@pytest.mark.parametrize("mode,gs", [("int4_sym", 32), ("int4_asym", 128), ("int8_asym", 64), ("nf4", 32), ("mxfp4", 32),
+                                     ("int4_asym", 30)])
+def test_se_estimate_matches_the_unfused_chain(mode, gs):
+    """nncf_amd_se_estimate == quantize -> get_target_zero_mask -> estimate_scales (scale_estimation.py:380-409)
+    composed from the tensor-level functions."""
+    from nncf_amd import _lib, scale_estimation as se, weight_lowering as wl
+    torch.manual_seed(3)
+    G = 1000
+    w = (torch.randn(G, gs, device="cuda") * 0.05).contiguous()
+    w[5] = 0.0
+    imp = torch.rand(G, gs, device="cuda")
+    cfg = _cfg(mode, gs)
+    if cfg.is_integer:
+        cw = wl.do_integer_quantization(w, cfg, (1,))
+        zp = cw.zero_point.to(torch.float32) if cw.zero_point is not None else None
+    else:
+        cw = wl.do_float_quantization(w, cfg, (1,))
+        zp = None
+    sc = (cw.scale * 0.9).reshape(G, 1).contiguous()
+    zp = zp.reshape(G, 1).contiguous() if zp is not None else None
+    if cfg.is_integer:
+        q = wl.do_integer_quantization(w, cfg, None, sc, zp).get_unscaled_tensor()
+    else:
+        q = wl.do_float_quantization(w, cfg, None, sc).get_unscaled_tensor()
+    target, zm = se.get_target_zero_mask(q, zp)
+    ref = se.estimate_scales(w, target, 0.001 * zm.to(torch.float32), imp)
+    out = torch.empty_like(sc)
+    _lib.check(_lib.lib().nncf_amd_se_estimate(_lib.ptr(w), _lib.ptr(imp), G, gs, _lib.MODE_ID[mode], _lib.ptr(sc), _lib.ptr(zp),
+                                               0.001, _lib.ptr(out), _lib.stream_of(w)))
+    np.testing.assert_allclose(host(out), host(ref), rtol=2e-6, atol=1e-7)
