@@ -251,3 +251,30 @@ def test_claim_counters_survive_many_launches():
     out = wl.compress_weight_packed(w, (1,), cfg)
     ref = wl.compress_weight(w, (1,), cfg)
     assert torch.equal(wl.pack_int4(ref.tensor), out.tensor)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
+@pytest.mark.parametrize("mode", ["int8_asym", "int8_sym", "int4_sym", "int4_asym"])
+def test_per_channel_row_kernel_all_classes(mode, dtype):
+    """Per-channel (group_size = -1) batched lowering: every team/keep class of the row kernel (rows of 8 ... 3584
+    16-byte vectors, wave- and block-owned), ragged row lengths inside a class, several classes in one call."""
+    from nncf_amd import weight_lowering as wl
+    rng = np.random.default_rng(11)
+    cols = [64, 200, 512, 1000, 2048, 4096, 5000, 8192, 14336, 28672] if dtype != "f32" else [32, 104, 520, 2048, 4096, 7168, 14336]
+    shapes = [(3 if c > 8000 else 9, c) for c in cols] + [(1, cols[2]), (70, cols[1])]
+    ws32 = [representable((rng.standard_normal(s) * 0.05).astype(np.float32), dtype) for s in shapes]
+    ws32[0][1, :] = 0.0                      # all-zero row
+    ws32[3][2, :] = ws32[3][2, 0]            # constant row
+    ws = [to_dev(w, dtype) for w in ws32]
+    cfg = _cfg(mode, -1)
+    got = wl.compress_weights_packed_batched(ws, cfg)
+    for w32, cw in zip(ws32, got):
+        rc, rs, rz = O.compress_weight(w32, (1,), mode, -1)
+        assert_equal_nan(host(cw.scale).reshape(rs.shape), rs, f"scale {w32.shape}")
+        if mode.startswith("int4"):
+            ref = O.pack_uint4(rc) if mode == "int4_asym" else O.pack_int4(rc)
+        else:
+            ref = rc
+        assert_equal_nan(host(cw.tensor).reshape(ref.shape), ref, f"codes {w32.shape}")
+        if rz is not None:
+            assert_equal_nan(host(cw.zero_point).reshape(rz.shape), rz, f"zp {w32.shape}")
