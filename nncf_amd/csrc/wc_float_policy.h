@@ -220,6 +220,7 @@ struct FloatPolicy {
             }
         }
     }
+    __device__ __forceinline__ void stat_merge(Stat& s, const Stat& o) const { s.amax = fmaxf(s.amax, o.amax); }
     __device__ __forceinline__ void stat_block(Stat& s, float* smem) const {
         s.amax = block_allreduce<4>(s.amax, OpMax(), smem);
     }

@@ -58,6 +58,10 @@ struct IntPolicyT {
             s.hi = fmaxf(s.hi, __shfl_xor(s.hi, 32, 64));
         }
     }
+    __device__ __forceinline__ void stat_merge(Stat& s, const Stat& o) const {
+        s.lo = fminf(s.lo, o.lo);
+        s.hi = fmaxf(s.hi, o.hi);
+    }
     __device__ __forceinline__ void stat_block(Stat& s, float* smem) const {
         s.lo = block_allreduce<4>(s.lo, OpMin(), smem);
         s.hi = block_allreduce<4>(s.hi, OpMax(), smem + 8);
@@ -211,8 +215,8 @@ struct IntPolicyT {
             if constexpr (N >= 16) {
 #pragma unroll
                 for (int j = 0; j < N / 16; ++j)
-                    ((uint4*)dst)[j] = make_uint4(bytes4(k + 16 * j), bytes4(k + 16 * j + 4), bytes4(k + 16 * j + 8),
-                                                  bytes4(k + 16 * j + 12));
+                    st<NT>((u32x4*)dst + j, u32x4{bytes4(k + 16 * j), bytes4(k + 16 * j + 4), bytes4(k + 16 * j + 8),
+                                                  bytes4(k + 16 * j + 12)});
             }
         }
     }

@@ -27,8 +27,13 @@ template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED>
 __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
     constexpr int E = Elem<DT>::kPerVec;
     __shared__ float lds[kPolicyLds];
-    __shared__ float smem[16];
-    __shared__ uint32_t claim_sh;
+    __shared__ typename Policy::Stat wave_stat[2][4];  // block teams: per-wave statistics, double-buffered
+    __shared__ uint32_t claim_sh[2];                    // block teams: the claimed row, double-buffered
+    int parity = 0;
+    // rows are staged by LDS-DMA: the next row lands in LDS while this one is processed from registers
+    // (wave-owned rows: a private image per wave; block-owned rows up to 32 KiB: one image per block)
+    constexpr bool DMA = TEAM == 64 || KEEP <= 8;
+    __shared__ Vec16 stage[TEAM == 64 ? 4 : 1][DMA ? TEAM * KEEP : 1];
     Policy::init_shared(lds);
     __syncthreads();
     GroupArgs o = {};
@@ -52,15 +57,15 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
         if constexpr (TEAM == 64) {
             return cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
         } else {
-            if (threadIdx.x == 0) claim_sh = claim;
+            // one barrier: the slot is rewritten two rounds later, with the statistics barrier in between
+            if (threadIdx.x == 0) claim_sh[parity] = claim;
             __syncthreads();
-            const uint32_t c = claim_sh;
-            __syncthreads();  // claim_sh is rewritten next round
-            return cbase + c;
+            return cbase + claim_sh[parity];
         }
     };
-    // The claim of the next row is in flight while this one is processed; its loads are issued only afterwards
-    // (a second register set for prefetching costs more in occupancy than it gains: measured).
+    // The claim of the next row is always in flight while this one is processed.  Block-owned rows are loaded
+    // straight into registers afterwards (a second register set for prefetching costs more in occupancy than it
+    // gains: measured); wave-owned rows (<= 8 KiB) are prefetched through LDS instead.
     struct Row {
         uint32_t vpr;
         uint64_t row;
@@ -83,21 +88,55 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
             if (j < d.vpr) dst[k] = load16_nt(src + j);
         }
     };
+    // vector owned by this thread in register k.  Block-owned rows: tl + k * TEAM (what the coalesced register
+    // loads give).  Wave-owned rows come out of LDS, so a lane can own PAIRS of adjacent vectors: its codes then
+    // leave as one 16-byte store per pair instead of two 8-byte ones.
+    constexpr bool PAIRS = DMA && KEEP >= 2;
+    auto vec_of = [&](int k) -> uint32_t {
+        return PAIRS ? (uint32_t)(2 * TEAM * (k >> 1) + 2 * tl + (k & 1)) : (uint32_t)(tl + k * TEAM);
+    };
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)stage[TEAM == 64 ? wave : 0];  // (unused without DMA)
+    auto issue_dma = [&](const Row& d) {  // every wave brings its 64-vector slices of the team's image
+        const char* tbase = (const char*)b.w[d.i] + d.row * d.vpr * 16;  // wave-uniform
+        const uint32_t last = (d.vpr - 1) * 16u;
+        const uint32_t w0 = TEAM == 64 ? 0u : (uint32_t)wave * 64u;
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            const uint32_t v = (uint32_t)(u * TEAM) + w0;  // first vector of this instruction
+            const uint32_t off = (v + lane) * 16u;
+            dma16_nt(tbase, off < last ? off : last, lds_base + v * 16u);
+        }
+    };
     claim_issue();
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
     uint32_t r = claim_take();
+    parity ^= 1;  // (block teams) the slot just read must not be rewritten before everybody has read it
     if (r >= hi) return;
-    Row cd = locate(r);
+    Row cd = locate(r), nd = cd;
     Vec16 cur[KEEP];
-    load_row(cd, cur);
+    if constexpr (DMA) issue_dma(cd);
+    else load_row(cd, cur);
     claim_issue();
     for (;;) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
-        const uint32_t rn = claim_take();
+        const uint32_t rn = claim_take();  // (block teams: contains the barrier after which the whole image has landed)
+        if constexpr (DMA) {
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) cur[k] = stage[TEAM == 64 ? wave : 0][vec_of(k)];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (TEAM == 64) {
+                if (rn < hi) {
+                    nd = locate(rn);
+                    issue_dma(nd);
+                    claim_issue();
+                }
+            }
+        }
         typename Policy::Stat st = pol.stat_init();
 #pragma unroll
         for (int k = 0; k < KEEP; ++k) {
-            const uint32_t j = tl + k * TEAM;
+            const uint32_t j = vec_of(k);
             __builtin_amdgcn_sched_barrier(0);
             if (j < cd.vpr) {
                 float f[E];
@@ -105,8 +144,22 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
                 pol.template stat_add_vec<E>(st, f);
             }
         }
-        if constexpr (TEAM == 64) pol.template stat_lanes<64>(st);
-        else pol.stat_block(st, smem);
+        pol.template stat_lanes<64>(st);
+        if constexpr (TEAM != 64) {
+            if (lane == 0) wave_stat[parity][wave] = st;
+            __syncthreads();  // also: everybody has copied the LDS image to registers, it may be overwritten
+            st = wave_stat[parity][0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) pol.stat_merge(st, wave_stat[parity][q]);
+            parity ^= 1;
+            if constexpr (DMA) {
+                if (rn < hi) {
+                    nd = locate(rn);
+                    issue_dma(nd);
+                    claim_issue();
+                }
+            }
+        }
         const typename Policy::Par par = pol.compute(st);
         o.scale_out = b.scale[cd.i];
         o.zp_out = (int32_t*)b.aux[cd.i];
@@ -115,24 +168,50 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
         else o.codes = b.packed[cd.i];
         // second unpack of the raw vectors (opaque, or the compiler keeps all KEEP*E floats of the first one
         // alive across the reduction) and one vector at a time (no interleaving: registers are what buys occupancy)
+        auto opaque = [](Vec16 raw) {
+            asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));
+            return raw;
+        };
+        if constexpr (PAIRS) {
 #pragma unroll
-        for (int k = 0; k < KEEP; ++k) {
-            const uint32_t j = tl + k * TEAM;
-            __builtin_amdgcn_sched_barrier(0);
-            if (j < cd.vpr) {
-                Vec16 raw = cur[k];
-                asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));
-                float f[E];
-                unpack<DT>(raw, f);
-                pol.template quant_n<E>(par, f, f);
-                pol.template store_codes<E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
+            for (int k = 0; k < KEEP; k += 2) {
+                const uint32_t j = vec_of(k);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < cd.vpr) {
+                    float f[2 * E];
+                    unpack<DT>(opaque(cur[k]), f);
+                    unpack<DT>(opaque(cur[k + 1]), f + E);
+                    pol.template quant_n<2 * E>(par, f, f);
+                    pol.template store_codes<2 * E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
+                } else if (j < cd.vpr) {
+                    float f[E];
+                    unpack<DT>(opaque(cur[k]), f);
+                    pol.template quant_n<E>(par, f, f);
+                    pol.template store_codes<E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const uint32_t j = vec_of(k);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j < cd.vpr) {
+                    float f[E];
+                    unpack<DT>(opaque(cur[k]), f);
+                    pol.template quant_n<E>(par, f, f);
+                    pol.template store_codes<E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (rn >= hi) break;
-        cd = locate(rn);
-        load_row(cd, cur);
-        claim_issue();
+        if constexpr (DMA) {
+            cd = nd;
+        } else {
+            cd = locate(rn);
+            load_row(cd, cur);
+            claim_issue();
+        }
     }
 }
 
