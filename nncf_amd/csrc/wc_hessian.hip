@@ -5,7 +5,7 @@
 // with an fp32 matmul.  Here X stays in its own dtype in HBM, is upcast while it is staged into LDS and
 // multiplied with the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fma chain, no reduced
 // precision), alpha = 2/n is applied once in the epilogue.  X^T X is symmetric: only tile pairs (ti <= tj) are
-// computed, the mirror image is written from the same accumulators.
+// computed and only the upper triangle is accumulated; a mirror pass (k_mirror_upper) writes the lower one.
 //
 // Tiling: block = 128x128 of H, 4 waves in 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).
 // K-step (tokens) = 16, double-buffered LDS image [16][128] per operand, k-major so that both MFMA operands
@@ -173,10 +173,9 @@ __global__ __launch_bounds__(256) void k_syrk(float* __restrict__ h, const void*
             for (int r = 0; r < 16; ++r) {
                 const int64_t gi = i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
                 const int64_t gj = j0 + wj * 64 + n * 32 + cl;
-                if (gi < K && gj < K) {
+                if (gi <= gj && gj < K) {  // upper triangle only: k_mirror_upper fills in the rest
                     const float val = alpha * acc[m][n][r];
                     atomicAdd(&h[gi * K + gj], val);
-                    if (ti != tj) atomicAdd(&h[gj * K + gi], val);
                 }
             }
 }
@@ -317,10 +316,9 @@ __global__ __launch_bounds__(256) void k_syrk16(float* __restrict__ h, const voi
             for (int r = 0; r < 16; ++r) {
                 const int64_t gi = i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
                 const int64_t gj = j0 + wj * 64 + n * 32 + cl;
-                if (gi < K && gj < K) {
+                if (gi <= gj && gj < K) {  // upper triangle only: k_mirror_upper fills in the rest
                     const float val = alpha * acc[m][n][r];
                     atomicAdd(&h[gi * K + gj], val);
-                    if (!diag) atomicAdd(&h[gj * K + gi], val);
                 }
             }
 }
@@ -476,7 +474,7 @@ __global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const vo
         }
 }
 
-// H[j][i] = H[i][j] for i < j: the 256x256 kernel accumulates the upper triangle only, so H comes out exactly
+// H[j][i] = H[i][j] for i < j: the SYRK kernels accumulate the upper triangle only, so H comes out exactly
 // symmetric whatever the order of the atomic partial sums.  64x64 tiles transposed through LDS: reads and writes
 // are row-contiguous.
 __global__ __launch_bounds__(256) void k_mirror_upper(float* __restrict__ h, uint32_t K) {
@@ -499,6 +497,12 @@ __global__ __launch_bounds__(256) void k_mirror_upper(float* __restrict__ h, uin
         const uint32_t row = j0 + r, col = i0 + c;  // element (row, col) of the lower triangle <- (col, row)
         if (row < K && col < row) h[(size_t)row * K + col] = t[c][r];
     }
+}
+
+static int mirror(float* h, int64_t k, hipStream_t s) {
+    const uint32_t mt = (uint32_t)((k + 63) / 64);
+    hipLaunchKernelGGL(k_mirror_upper, dim3(mt * (mt + 1) / 2), dim3(256), 0, s, h, (uint32_t)k);
+    return launch_status("hessian_mirror");
 }
 
 }  // namespace wc
@@ -562,15 +566,15 @@ extern "C" int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype,
                 hipLaunchKernelGGL((k_syrk16b<NNCF_AMD_F16>), g16, dim3(256), lds_bytes, s, h, x, tokens, k, alpha, nt, rps);
             int st16 = launch_status("hessian_syrk16b");
             if (st16 != NNCF_AMD_OK) return st16;
-            const uint32_t mt = (uint32_t)((k + 63) / 64);
-            hipLaunchKernelGGL(k_mirror_upper, dim3(mt * (mt + 1) / 2), dim3(256), 0, s, h, (uint32_t)k);
-            return launch_status("hessian_mirror");
+            return mirror(h, k, s);
         }
         if (x_dtype == NNCF_AMD_BF16)
             hipLaunchKernelGGL((k_syrk16<NNCF_AMD_BF16>), g16, dim3(256), 0, s, h, x, tokens, k, alpha, nt, rps);
         else
             hipLaunchKernelGGL((k_syrk16<NNCF_AMD_F16>), g16, dim3(256), 0, s, h, x, tokens, k, alpha, nt, rps);
-        return launch_status("hessian_syrk16");
+        int st16 = launch_status("hessian_syrk16");
+        if (st16 != NNCF_AMD_OK) return st16;
+        return mirror(h, k, s);
     }
 #define LAUNCH(DT)                                                                                                      \
     if (vec)                                                                                                            \
@@ -586,5 +590,7 @@ extern "C" int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype,
             return NNCF_AMD_ERR_DTYPE;
     }
 #undef LAUNCH
-    return launch_status("hessian_syrk");
+    int st32 = launch_status("hessian_syrk");
+    if (st32 != NNCF_AMD_OK) return st32;
+    return mirror(h, k, s);
 }
