@@ -220,6 +220,21 @@ int nncf_amd_gptq_block(const float* weight, float* quantized, float* err_block,
                         int64_t k, int64_t i1, int64_t count, int64_t group_size, int mode, float* scales,
                         int32_t* zps, int use_given_params, void* stream);
 
+/*
+ * Decompressor forward: packed codes -> weights in the layer's dtype in one pass.
+ * Replaces INT8/INT4{Asymmetric,Symmetric}WeightsDecompressor.forward (src/nncf/torch/quantization/layers.py:1303-1460)
+ * = unpack_uint4/unpack_int4 + decompress_asymmetric/decompress_symmetric
+ * (src/nncf/torch/quantization/quantize_functions.py:389-473) + reshape + cast, with the reference's arithmetic:
+ * d = code - zero_point, v = round_to_scale_dtype(d * scale), out = cast(v).  NF4 / MXFP4 (no torch decompressor in
+ * the reference) use the code book value for d.
+ *   codes: INT8: 1 byte per element; 4-bit modes: 2 elements per byte, low nibble first (INT4_SYM stored +8).
+ *   scale: [n_groups], scale_kind 0 = fp32, 1 = fp16 (what the reference's modules hold), 3 = E8M0 bytes (MXFP4).
+ *   zero_point: INT8_ASYM uint8 [n_groups]; INT4_ASYM two per byte (pack_uint4 of the zero points); else NULL.
+ *   out: [n_groups * group_size] of out_dtype (nncf_amd_dtype).
+ */
+int nncf_amd_decompress(const uint8_t* codes, int mode, int64_t n_groups, int64_t group_size, const void* scale,
+                        int scale_kind, const uint8_t* zero_point, void* out, int out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

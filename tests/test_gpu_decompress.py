@@ -1,0 +1,118 @@
+"""GPU parity: fused decompressor forward vs the reference's torch op chain (unpack + decompress_* + reshape + cast,
+quantize_functions.py:389-473, layers.py:1303-1460), restated here op for op in torch -- bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wc_oracle as O
+from tests.gpu_utils import host, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(mode, gs):
+    from nncf_amd.parameters import WeightCompressionConfig
+    return WeightCompressionConfig(mode=mode, group_size=gs)
+
+
+def _unpack_uint4(p):  # quantize_functions.py:437-445
+    return torch.stack((torch.bitwise_and(p, 15), torch.bitwise_right_shift(p, 4)), dim=-1)
+
+
+def _ref_asym(x, scale, zp):  # decompress_asymmetric :389-401
+    x = x.type(dtype=scale.dtype)
+    zp = zp.type(dtype=scale.dtype)
+    return (x - zp) * scale
+
+
+def _ref_sym(x, scale):  # decompress_symmetric :404-414
+    return x.type(dtype=scale.dtype) * scale
+
+
+@pytest.mark.parametrize("result_dtype", [torch.float16, torch.bfloat16, torch.float32, None])
+@pytest.mark.parametrize("mode,gs", [("int4_sym", 128), ("int4_asym", 64), ("int4_sym", 8), ("int4_asym", -1), ("int4_sym", 20)])
+def test_int4_decompressors_match_the_torch_chain(mode, gs, result_dtype):
+    from nncf_amd import decompressors as D, weight_lowering as wl
+    torch.manual_seed(0)
+    shape = (48, 640)
+    w = (torch.randn(shape, device="cuda") * 0.05).to(torch.bfloat16)
+    cw = wl.compress_weight(w, (1,), _cfg(mode, gs))
+    cshape = tuple(cw.tensor.shape)
+    if mode == "int4_sym":
+        dec = D.INT4SymmetricWeightsDecompressor(cw.scale, cshape, shape, result_dtype)
+        packed = dec.pack_weight(cw.tensor)
+        x = (_unpack_uint4(packed).type(torch.int8) - 8).reshape(cshape)
+        ref = _ref_sym(x, cw.scale.type(torch.float16))
+    else:
+        dec = D.INT4AsymmetricWeightsDecompressor(cw.scale, cw.zero_point, cshape, shape, result_dtype)
+        packed = dec.pack_weight(cw.tensor)
+        x = _unpack_uint4(packed).reshape(cshape)
+        zp = _unpack_uint4(dec._zero_point).reshape(cw.zero_point.shape)
+        ref = _ref_asym(x, cw.scale.type(torch.float16), zp)
+    ref = ref.reshape(shape)
+    ref = ref.type(result_dtype) if result_dtype is not None else ref
+    got = dec.cuda()(packed)
+    assert got.dtype == ref.dtype and got.shape == ref.shape
+    assert torch.equal(got, ref)
+    # the fused compress output is what the module consumes
+    fused = wl.compress_weight_packed(w, (1,), _cfg(mode, gs))
+    assert torch.equal(dec(fused.tensor), ref)
+
+
+@pytest.mark.parametrize("result_dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("mode", ["int8_asym", "int8_sym"])
+@pytest.mark.parametrize("shape", [(40, 512), (7, 100)])
+def test_int8_decompressors_match_the_torch_chain(mode, shape, result_dtype):
+    from nncf_amd import decompressors as D, weight_lowering as wl
+    torch.manual_seed(1)
+    w = (torch.randn(shape, device="cuda") * 0.05).to(torch.float16)
+    cw = wl.compress_weight(w, (1,), _cfg(mode, -1))
+    if mode == "int8_asym":
+        dec = D.INT8AsymmetricWeightsDecompressor(cw.scale, cw.zero_point, result_dtype).cuda()
+        x = dec.pack_weight(cw.tensor)
+        ref = _ref_asym(x, cw.scale.type(torch.float16), dec._zero_point)
+    else:
+        dec = D.INT8SymmetricWeightsDecompressor(cw.scale, result_dtype).cuda()
+        x = dec.pack_weight(cw.tensor)
+        ref = _ref_sym(x, cw.scale.type(torch.float16))
+    assert torch.equal(dec(x), ref.type(result_dtype))
+
+
+@pytest.mark.parametrize("mode", ["nf4", "mxfp4"])
+def test_float_codebook_decompressors(mode):
+    """f1: decompressed weight == oracle do_float_dequantization (fp32 result; MXFP4 exact, NF4 through the fp16
+    scale the module stores)."""
+    from nncf_amd import decompressors as D, weight_lowering as wl
+    rng = np.random.default_rng(2)
+    w32 = (rng.standard_normal((32, 256)) * 0.05).astype(np.float32)
+    w = to_dev(w32, "bf16")
+    w32 = host(w.float())
+    got = wl.compress_weights_packed_batched([w], _cfg(mode, 32), want_e8m0=True)[0]
+    rv, rs, _ = O.compress_weight(w32, (1,), mode, 32)
+    cshape = rv.shape
+    if mode == "mxfp4":
+        dec = D.MXFP4WeightsDecompressor(got.codebook, cshape, (32, 256), torch.float32)
+        ref = (rv * rs).reshape(32, 256)
+        assert np.array_equal(host(dec(got.tensor)), ref)
+        assert np.array_equal(host(D.MXFP4WeightsDecompressor(got.codebook, cshape, (32, 256), torch.bfloat16)(got.tensor).float()),
+                              host(torch.from_numpy(ref).to(torch.bfloat16).float()))
+    else:
+        dec = D.NF4WeightsDecompressor(got.scale, cshape, (32, 256), torch.float32)
+        s16 = rs.astype(np.float16)
+        ref = (rv.astype(np.float16) * s16).astype(np.float32).reshape(32, 256)  # code book value and product in fp16
+        assert np.array_equal(host(dec(got.tensor)), ref)
+        np.testing.assert_allclose(host(dec(got.tensor)), (rv * rs).reshape(32, 256), rtol=2e-3, atol=1e-6)
+
+
+def test_decompress_large_roundtrip_property():
+    """Llama-sized tensor: decompress(compress(w)) == integer_quantize_dequantize(w) computed with the fp16 scale."""
+    from nncf_amd import decompressors as D, weight_lowering as wl
+    torch.manual_seed(4)
+    w = (torch.randn(4096, 4096, device="cuda") * 0.02).to(torch.bfloat16)
+    cfg = _cfg("int4_sym", 128)
+    cw = wl.compress_weight(w, (1,), cfg)
+    fused = wl.compress_weight_packed(w, (1,), cfg)
+    dec = D.INT4SymmetricWeightsDecompressor(cw.scale, tuple(cw.tensor.shape), (4096, 4096), torch.bfloat16)
+    out = dec(fused.tensor)
+    ref = (cw.tensor.type(torch.float16) * cw.scale.type(torch.float16)).reshape(4096, 4096).type(torch.bfloat16)
+    assert torch.equal(out, ref)

@@ -54,6 +54,19 @@ def main():
     sc = w.abs().amax(-1, keepdim=True) / 8
     t = timeit(lambda: wl.integer_quantize_dequantize_weight(w, cfg, None, sc))
     out["qdq_fp32_4096x4096_g128"] = {"us": t * 1e6, "GBps_alg": w.numel() * 8 / t / 1e9}
+    # decompressor forward (f2): packed int4 -> bf16, 14336 x 4096 g128
+    from nncf_amd import decompressors as D
+    wb = (torch.randn((14336, 4096), device=dev) * 0.02).to(torch.bfloat16)
+    cw = wl.compress_weight(wb, (1,), cfg)
+    fused = wl.compress_weight_packed(wb, (1,), cfg)
+    dec = D.INT4SymmetricWeightsDecompressor(cw.scale, tuple(cw.tensor.shape), (14336, 4096), torch.bfloat16).cuda()
+    t = timeit(lambda: dec(fused.tensor))
+    n = wb.numel()
+    out["decompress_int4sym_14336x4096_bf16"] = {"us": t * 1e6, "GBps_alg": n * (0.5 + 2 + 2 / 128) / t / 1e9}
+    from nncf_amd.weight_lowering import unpack_int4
+    s16 = cw.scale.half()
+    t = timeit(lambda: (unpack_int4(fused.tensor).reshape(cw.tensor.shape).half() * s16).reshape(14336, 4096).to(torch.bfloat16))
+    out["decompress_torch_chain"] = {"us": t * 1e6}
     print(json.dumps(out, indent=1))
 
 
