@@ -1,0 +1,154 @@
+"""Layer-wise input feeder for GPTQ on torch models: what the reference's OpenVINO-only
+`LayerwiseEngine` does for GPTQ.apply (src/nncf/quantization/algorithms/layerwise/engine.py:145-170,
+openvino_iterator.py:166-229; consumed at gptq.py:116-144) -- every target Linear sees the activations produced by
+the model whose EARLIER Linears are already quantized.
+
+MI355X-first shape of it:
+* the raw activations X are never stored: each calibration sample streams through `nncf_amd_hessian_accumulate`
+  (MFMA SYRK, running average of gptq.py:237-240) and the fused token-mean reducer while the hooked forward runs,
+  then the forward is cut short (the rest of the model is not needed);
+* Linears that read one activation (q/k/v, gate/up) form one group: ONE Hessian serves all of them;
+* finished decoder blocks (children of an nn.ModuleList) are short-circuited: their forward returns the cached
+  output of the latest finished block, so a pass costs the unfinished part of one block, not the model prefix.
+  This assumes the blocks of a ModuleList run as a chain (decoder-only transformers); `short_circuit=False` runs the
+  real prefix instead.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from nncf_amd import _lib
+from nncf_amd.statistics import WCTensorStatistic, activation_stats
+
+
+class _EarlyExit(Exception):
+    pass
+
+
+def _detach(out):
+    if isinstance(out, torch.Tensor):
+        return out.detach()
+    if isinstance(out, (tuple, list)):
+        return type(out)(_detach(o) for o in out)
+    if isinstance(out, dict):
+        return {k: _detach(v) for k, v in out.items()}
+    return out
+
+
+class LayerwiseFeeder:
+    def __init__(self, model: nn.Module, dataset, subset_size: int, trace, target_names: List[str],
+                 short_circuit: bool = True):
+        from nncf_amd.quantize_model import _forward, _model_device, _to_device
+
+        self._model, self._forward_fn = model, _forward
+        device = _model_device(model)
+        self._samples = []
+        for i, item in enumerate(dataset.get_inference_data()):
+            if i >= subset_size:
+                break
+            self._samples.append(_to_device(item, device))
+        if not self._samples:
+            raise ValueError("GPTQ needs a non-empty calibration dataset")
+        mods = dict(model.named_modules())
+        order = {n: i for i, n in enumerate(trace.order)}
+        targets = sorted((n for n in target_names if n in trace.act_key), key=lambda n: order[n])
+        # groups of Linears reading the same activation, in execution order of their first member
+        groups: Dict[int, List[str]] = {}
+        for n in targets:
+            groups.setdefault(trace.act_key[n], []).append(n)
+        self._groups = sorted(groups.values(), key=lambda g: order[g[0]])
+        self._mods = mods
+        # decoder blocks: children of ModuleLists that hold targets
+        self._block_of: Dict[str, Optional[str]] = {}
+        block_names = []
+        if short_circuit:
+            for lname, lmod in mods.items():
+                if isinstance(lmod, nn.ModuleList):
+                    for idx in range(len(lmod)):
+                        block_names.append(f"{lname}.{idx}" if lname else str(idx))
+        for n in targets:
+            owner = [b for b in block_names if n.startswith(b + ".")]
+            self._block_of[n] = min(owner, key=len) if owner else None  # outermost stack
+        self._patched: List[nn.Module] = []
+        self._cache: Optional[List] = None
+        self._cur = 0
+
+    # -------------------------------------------------------------------------------------------------
+    def _run(self, hook_module: nn.Module, pre_hook=None, post_hook=None) -> None:
+        h = (hook_module.register_forward_pre_hook(pre_hook, with_kwargs=True) if pre_hook is not None
+             else hook_module.register_forward_hook(post_hook))
+        try:
+            with torch.no_grad():
+                for i, item in enumerate(self._samples):
+                    self._cur = i
+                    try:
+                        self._forward_fn(self._model, item)
+                    except _EarlyExit:
+                        pass
+        finally:
+            h.remove()
+
+    def _finish_block(self, block_name: str) -> None:
+        """Outputs of the finished block for every sample; from now on the block (and every block finished before
+        it) returns them instead of running."""
+        block = self._mods[block_name]
+        outs: List = [None] * len(self._samples)
+
+        def post(mod, args, output):
+            outs[self._cur] = _detach(output)
+            raise _EarlyExit
+
+        self._run(block, post_hook=post)
+        if any(o is None for o in outs):  # the block did not run for some sample: leave it unpatched
+            return
+        self._cache = outs
+        block.forward = lambda *a, **k: self._cache[self._cur]
+        self._patched.append(block)
+
+    def _restore(self) -> None:
+        for b in self._patched:
+            if "forward" in b.__dict__:
+                del b.__dict__["forward"]
+        self._patched = []
+        self._cache = None
+
+    def __iter__(self) -> Iterator[Tuple[List[str], torch.Tensor, WCTensorStatistic]]:
+        L = _lib.lib()
+        try:
+            for gi, group in enumerate(self._groups):
+                first = self._mods[group[0]]
+                k = first.in_features
+                H = torch.zeros((k, k), dtype=torch.float32, device=first.weight.device)
+                stats = WCTensorStatistic()
+                state = {"n": 0}
+
+                def pre(mod, args, kwargs, H=H, stats=stats, state=state, k=k):
+                    x = args[0] if args else next(iter(kwargs.values()))
+                    if x.dtype == torch.float64:
+                        x = x.float()
+                    bs = x.shape[0] if x.ndim == 3 else 1  # gptq.py:226-235
+                    x2 = x.reshape(-1, k).contiguous()
+                    n = state["n"]
+                    beta = n / (n + bs)
+                    n += bs
+                    state["n"] = n
+                    with torch.cuda.device(x2.device):
+                        _lib.check(L.nncf_amd_hessian_accumulate(_lib.ptr(H), _lib.ptr(x2), _lib.dtype_id(x2), x2.shape[0],
+                                                                 k, 2.0 / n, beta, _lib.stream_of(x2)))
+                    mean, _ = activation_stats(x2.reshape(1, -1, k), want_stats=False)
+                    stats.mean_values.append(mean.to(x.dtype))
+                    stats.shape_values.append(tuple(x.shape))
+                    raise _EarlyExit
+
+                self._run(first, pre_hook=pre)
+                yield group, H, stats
+                # the caller has replaced the weights of `group` by now; close the block if this was its last group
+                blk = self._block_of.get(group[0])
+                nxt = self._groups[gi + 1] if gi + 1 < len(self._groups) else None
+                if blk is not None and nxt is not None and self._block_of.get(nxt[0]) != blk:
+                    self._finish_block(blk)
+        finally:
+            self._restore()

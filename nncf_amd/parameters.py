@@ -74,3 +74,114 @@ class CompressedWeight:
         if self.tensor is not None and self.codebook is not None:
             return self.codebook[self.tensor]
         return self.tensor
+
+
+# ---------------------------------------------------------------- model-level API types (quantize_model.py)
+class BackupMode(Enum):
+    """src/nncf/parameters.py:165-182 (the FP8 backups are outside this build's scope)."""
+    NONE = "none"
+    INT8_SYM = "int8_sym"
+    INT8_ASYM = "int8_asym"
+    MXFP8_E4M3 = "mxfp8_e4m3"
+    FP8_E4M3 = "fp8_e4m3"
+
+
+class SensitivityMetric(Enum):
+    """src/nncf/parameters.py:186-209."""
+    WEIGHT_QUANTIZATION_ERROR = "weight_quantization_error"
+    HESSIAN_INPUT_ACTIVATION = "hessian_input_activation"
+    MEAN_ACTIVATION_VARIANCE = "mean_activation_variance"
+    MAX_ACTIVATION_VARIANCE = "max_activation_variance"
+    MEAN_ACTIVATION_MAGNITUDE = "mean_activation_magnitude"
+
+
+class GroupSizeFallbackMode(Enum):
+    """src/nncf/quantization/advanced_parameters.py:77-96."""
+    ERROR = "error"
+    IGNORE = "ignore"
+    ADJUST = "adjust"
+
+
+def enum_of(cls, value):
+    """Accepts this package's enum, the reference's enum of the same name (same .value strings) or a string."""
+    if isinstance(value, cls):
+        return value
+    return cls(getattr(value, "value", value))
+
+
+@dataclass
+class AdvancedAWQParameters:
+    """advanced_parameters.py:288-312."""
+    subset_size: int = 32
+    percent_to_apply: float = 0.002
+    alpha_min: float = 0.0
+    alpha_max: float = 1.0
+    steps: int = 100
+    prefer_data_aware_scaling: bool = True
+
+
+@dataclass
+class AdvancedScaleEstimationParameters:
+    """advanced_parameters.py:317-335."""
+    subset_size: int = 64
+    initial_steps: int = 5
+    scale_steps: int = 5
+    weight_penalty: float = -1.0
+
+
+@dataclass
+class AdvancedGPTQParameters:
+    """advanced_parameters.py:340-355."""
+    damp_percent: float = 0.1
+    block_size: int = 128
+    subset_size: int = 128
+
+
+@dataclass
+class AdvancedCompressionParameters:
+    """advanced_parameters.py:407-452, the fields of the modes this build covers."""
+    group_size_fallback_mode: GroupSizeFallbackMode = GroupSizeFallbackMode.ERROR
+    min_adjusted_group_size: int = 32
+    awq_params: AdvancedAWQParameters = None
+    scale_estimation_params: AdvancedScaleEstimationParameters = None
+    gptq_params: AdvancedGPTQParameters = None
+    statistics_path: Optional[str] = None
+
+    def __post_init__(self) -> None:
+        self.awq_params = self.awq_params or AdvancedAWQParameters()
+        self.scale_estimation_params = self.scale_estimation_params or AdvancedScaleEstimationParameters()
+        self.gptq_params = self.gptq_params or AdvancedGPTQParameters()
+
+
+@dataclass
+class IgnoredScope:
+    """src/nncf/scopes.py IgnoredScope, keyed on module qualified names (there is no NNCF graph here): `names` are
+    exact module names ("model.layers.3.mlp.down_proj"), `patterns` regular expressions matched on them, `types`
+    a subset of {"linear", "embedding"}."""
+    names: tuple = ()
+    patterns: tuple = ()
+    types: tuple = ()
+    validate: bool = True
+
+
+class Dataset:
+    """src/nncf/data/dataset.py: an iterable of model inputs plus an optional transform."""
+
+    def __init__(self, data_source, transform_func=None):
+        self._data_source = data_source
+        self._transform_func = transform_func
+
+    def get_inference_data(self, indices=None):
+        wanted = None if indices is None else set(indices)
+        for i, item in enumerate(self._data_source):
+            if wanted is not None and i not in wanted:
+                if i > max(wanted, default=-1):
+                    break
+                continue
+            yield self._transform_func(item) if self._transform_func is not None else item
+
+    def get_length(self):
+        try:
+            return len(self._data_source)
+        except TypeError:
+            return None
