@@ -21,65 +21,96 @@ from nncf_amd.parameters import WeightCompressionConfig, as_config
 from nncf_amd.statistics import WCTensorStatistic, activations_to_wc_statistics
 
 
+HESSIAN_CHUNK_TOKENS = 32768  # tokens per SYRK launch: the MFMA kernel reaches its rate from ~16k tokens on
+HESSIAN_CHUNK_BYTES = 1 << 30
+
+
+class HessianAccumulator:
+    """Running average of gptq.py:237-240, `H <- H n/(n+b) + (2/(n+b)) X^T X`, for a stream of calibration items.
+    Items are buffered and concatenated into chunks of ~32k tokens per SYRK launch: by induction the chunked update
+    with b = sum of the items' batch sizes equals the item-by-item recursion exactly (as real arithmetic), and one
+    long launch runs the MFMA kernel at 3x the rate of sixteen 2048-token ones."""
+
+    def __init__(self, k: int, device, chunk_tokens: int = HESSIAN_CHUNK_TOKENS):
+        self.k, self.nsamples, self._chunk_tokens = k, 0, chunk_tokens
+        self.H = torch.zeros((k, k), dtype=torch.float32, device=device)
+        self._buf: List[torch.Tensor] = []
+        self._buf_tokens = self._buf_bs = 0
+
+    def add(self, x2d: torch.Tensor, batch_size: int) -> None:
+        """x2d [tokens, K] (any float dtype the kernel takes); batch_size = the item's contribution to n."""
+        if self._buf and self._buf[0].dtype != x2d.dtype:
+            self.flush()
+        self._buf.append(x2d)
+        self._buf_tokens += x2d.shape[0]
+        self._buf_bs += batch_size
+        if (self._buf_tokens >= self._chunk_tokens
+                or self._buf_tokens * self.k * x2d.element_size() >= HESSIAN_CHUNK_BYTES):
+            self.flush()
+
+    def flush(self) -> None:
+        if not self._buf:
+            return
+        x = self._buf[0] if len(self._buf) == 1 else torch.cat(self._buf, dim=0)
+        x = x.contiguous()
+        n, bs = self.nsamples, self._buf_bs
+        beta = n / (n + bs)
+        self.nsamples = n + bs
+        alpha = 2.0 / self.nsamples
+        with torch.cuda.device(x.device):
+            st = _lib.lib().nncf_amd_hessian_accumulate(_lib.ptr(self.H), _lib.ptr(x), _lib.dtype_id(x), x.shape[0],
+                                                        self.k, alpha, beta, _lib.stream_of(x))
+        _lib.check(st)
+        self._buf, self._buf_tokens, self._buf_bs = [], 0, 0
+
+    def result(self) -> torch.Tensor:
+        self.flush()
+        return self.H
+
+
 def calculate_hessian(inputs: List[torch.Tensor], is_3d_weight: bool = False) -> torch.Tensor:
     """gptq.py:200-242 for a matmul node with non-transposed activations.  Returns fp32 [batch, K, K]."""
     first = inputs[0]
     _lib.require_gpu(first, "calculate_hessian")
     k = first.shape[-1]
     hb = 1 if not is_3d_weight else reduce(mul, first.shape[:-2], 1)
-    H = torch.zeros((hb, k, k), dtype=torch.float32, device=first.device)
-    L = _lib.lib()
-    nsamples = 0
+    accs = [HessianAccumulator(k, first.device) for _ in range(hb)]
     for inp in inputs:
         is_3d_act = inp.ndim == 3
         batch_size = 1 if is_3d_weight or not is_3d_act else inp.shape[0]
         if inp.dtype == torch.float64:
             inp = inp.float()
-        if is_3d_act and not is_3d_weight:
-            xs = [inp.reshape(-1, k)]
-        elif is_3d_weight:
-            xs = list(inp.reshape(hb, -1, k))
-        else:
-            xs = [inp.reshape(-1, k)]
-        beta = nsamples / (nsamples + batch_size)
-        nsamples += batch_size
-        alpha = 2.0 / nsamples
-        with torch.cuda.device(first.device):
-            for b, x in enumerate(xs):
-                x = x.contiguous()
-                st = L.nncf_amd_hessian_accumulate(_lib.ptr(H[b]), _lib.ptr(x), _lib.dtype_id(x), x.shape[0], k,
-                                                   alpha, beta, _lib.stream_of(x))
-                _lib.check(st)
-    return H
+        xs = list(inp.reshape(hb, -1, k)) if is_3d_weight else [inp.reshape(-1, k)]
+        for acc, x in zip(accs, xs):
+            acc.add(x, batch_size)
+    return torch.stack([acc.result() for acc in accs])
 
 
 def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: WeightCompressionConfig,
                      inputs: Optional[List[torch.Tensor]] = None, damp_percent: float = 0.1, block_size: int = 128,
                      scale_estimation: bool = False, reduction_axes=(1,),
-                     input_stats: Optional[WCTensorStatistic] = None):
+                     input_stats: Optional[WCTensorStatistic] = None, hinv: Optional[torch.Tensor] = None,
+                     dead: Optional[torch.Tensor] = None):
     """gptq.py:244-379.  hessian [K, K] and weight [N, K] fp32 are modified in place like the reference does.
     Returns (quantized fp32 [N, K], scales [N, K/gs, 1] (or [N, 1] for group_size -1), zero_points | None).
     `input_stats` (token means over the FULL hidden axis, one per sample) may stand in for `inputs` when scale
-    estimation is on: the mean of a column slice is the slice of the mean (gptq.py:320-321, 381-396)."""
+    estimation is on: the mean of a column slice is the slice of the mean (gptq.py:320-321, 381-396).
+    `hinv`, `dead` = a `prepare_hinv(hessian)` result to share between weights that read the same activation
+    (`hessian` may then be None)."""
     config = as_config(config)
     _lib.require_gpu(weight, "quantize_weights")
-    assert hessian.ndim == 2, "Hessian should be 2D"
     if tuple(reduction_axes) != (1,) or weight.ndim != 2:
         raise UnsupportedModelError("nncf_amd GPTQ expects a [out, in] weight reduced along axis 1")
     if block_size > 128:
         raise UnsupportedModelError("nncf_amd GPTQ block_size must be <= 128")
     W = weight
-    assert W.dtype == torch.float32 and W.is_contiguous() and hessian.dtype == torch.float32
+    assert W.dtype == torch.float32 and W.is_contiguous()
     N, K = W.shape
-    dead = torch.diag(hessian) == 0
-    idx = torch.arange(K, device=W.device)
-    hessian[idx[dead], idx[dead]] = 1
+    if hinv is None:
+        hinv, dead = prepare_hinv(hessian, damp_percent)
     W[:, dead] = 0
     gs = config.group_size if config.group_size != -1 else K
     ngroups = K // gs
-    damp = damp_percent * torch.mean(torch.diag(hessian))
-    hessian[idx, idx] += damp
-    hinv = _upper_cholesky_of_inverse(hessian)
 
     asym = config.is_integer and config.is_asym_mode
     Q = torch.zeros_like(W)
@@ -124,16 +155,127 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
     return Q, out_scales, out_zps
 
 
+CHOLINV_BASE = 1024  # below this size the LAPACK-style routines (rocSOLVER potrf, rocBLAS trsm) are used directly
+
+
+TRI_SPLIT_MIN = 2048  # triangular-aware products split down to this size
+
+
+def _mm_dense_lowerT(X: torch.Tensor, T: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """X @ T^T for lower-triangular T, skipping T's zero block: with T = [[T11, 0], [T21, T22]],
+    X T^T = [X1 T11^T, X1 T21^T + X2 T22^T] (3 of the 4 quarter products; recursively towards half the flops)."""
+    n = T.shape[0]
+    if out is None:
+        out = torch.empty((X.shape[0], n), dtype=X.dtype, device=X.device)
+    if n < TRI_SPLIT_MIN:
+        return torch.matmul(X, T.T, out=out)
+    h = ((n // 2 + 127) // 128) * 128
+    _mm_dense_lowerT(X[:, :h], T[:h, :h], out[:, :h])
+    _mm_dense_lowerT(X[:, h:], T[h:, h:], out[:, h:])
+    out[:, h:].addmm_(X[:, :h], T[h:, :h].T)
+    return out
+
+
+def _mm_dense_lower(X: torch.Tensor, T: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """X @ T for lower-triangular T: [X1 T11 + X2 T21, X2 T22]."""
+    n = T.shape[0]
+    if out is None:
+        out = torch.empty((X.shape[0], n), dtype=X.dtype, device=X.device)
+    if n < TRI_SPLIT_MIN:
+        return torch.matmul(X, T, out=out)
+    h = ((n // 2 + 127) // 128) * 128
+    _mm_dense_lower(X[:, :h], T[:h, :h], out[:, :h])
+    _mm_dense_lower(X[:, h:], T[h:, h:], out[:, h:])
+    out[:, :h].addmm_(X[:, h:], T[h:, :h])
+    return out
+
+
+def _mm_lower_dense(T: torch.Tensor, X: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """T @ X for lower-triangular T: [[T11 X1], [T21 X1 + T22 X2]]."""
+    n = T.shape[0]
+    if n < TRI_SPLIT_MIN:
+        return torch.matmul(T, X, out=out)
+    h = ((n // 2 + 127) // 128) * 128
+    _mm_lower_dense(T[:h, :h], X[:h], out[:h])
+    _mm_lower_dense(T[h:, h:], X[h:], out[h:])
+    out[h:].addmm_(T[h:, :h], X[:h])
+    return out
+
+
+def _syrk_lower_sub(C: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
+    """Lower triangle of C - A A^T into a new matrix (the strictly upper part is left unspecified: only the lower
+    triangle of a Schur complement is ever read)."""
+    n = C.shape[0]
+    S = torch.empty_like(C)
+
+    def rec(S, C, A):
+        m = C.shape[0]
+        if m < TRI_SPLIT_MIN:
+            torch.addmm(C, A, A.T, beta=1.0, alpha=-1.0, out=S)
+            return
+        h = ((m // 2 + 127) // 128) * 128
+        rec(S[:h, :h], C[:h, :h], A[:h])
+        rec(S[h:, h:], C[h:, h:], A[h:])
+        torch.addmm(C[h:, :h], A[h:], A[:h].T, beta=1.0, alpha=-1.0, out=S[h:, :h])
+
+    rec(S, C, A)
+    return S
+
+
+def _cholinv_lower(A: torch.Tensor, Linv: torch.Tensor) -> None:
+    """Writes L^-1 (lower triangle; the caller zero-fills the rest) of the SPD matrix A = L L^T into `Linv`; only
+    the lower triangle of A is read.  With A = [[A11, .], [A21, A22]]:
+        I11 = rec(A11);  L21 = A21 I11^T;  S = A22 - L21 L21^T;  I22 = rec(S);  I21 = -I22 (L21 I11)
+    i.e. everything above the base size is a plain fp32 GEMM (hipBLASLt runs them at ~150 TFLOP/s on MI355X, the
+    library potrf / trsm chain at 35-60), and the inverse factor comes out of ONE sweep instead of a factorization
+    plus a triangular solve against the identity.  The products with a triangular operand and the symmetric Schur
+    complement skip their zero / redundant blocks."""
+    n = A.shape[0]
+    if n <= CHOLINV_BASE:
+        L = torch.linalg.cholesky(A)
+        eye = torch.eye(n, dtype=A.dtype, device=A.device)
+        Linv.copy_(torch.linalg.solve_triangular(L, eye, upper=False))
+        return
+    h = ((n // 2 + 127) // 128) * 128
+    if h >= n:
+        h = n // 2
+    I11 = Linv[:h, :h]
+    _cholinv_lower(A[:h, :h], I11)
+    L21 = _mm_dense_lowerT(A[h:, :h], I11)
+    S = _syrk_lower_sub(A[h:, h:], L21)
+    _cholinv_lower(S, Linv[h:, h:])
+    del S
+    tmp = _mm_dense_lower(L21, I11)
+    del L21
+    _mm_lower_dense(Linv[h:, h:], tmp, Linv[h:, :h])
+    Linv[h:, :h].neg_()
+
+
 def _upper_cholesky_of_inverse(hessian: torch.Tensor) -> torch.Tensor:
     """U upper triangular with H^-1 = U^T U: what the reference gets from cholesky -> cholesky_inverse ->
     cholesky(upper=True) (gptq.py:283-285), from ONE factorization instead of two plus an inversion.  With J the
     index reversal, J H J = L L^T (plain Cholesky) gives H = R R^T for the upper triangular R = J L J, hence
-    H^-1 = R^-T R^-1 = U^T U with U = R^-1, and a Cholesky factor with positive diagonal is unique.  In fp32 this is
-    at least as close to the exact U as the three-step chain (one rounding cascade less)."""
-    L = torch.linalg.cholesky(torch.flip(hessian, (0, 1)))
-    R = torch.flip(L, (0, 1))
-    eye = torch.eye(hessian.shape[0], dtype=hessian.dtype, device=hessian.device)
-    return torch.linalg.solve_triangular(R, eye, upper=True).contiguous()
+    H^-1 = R^-T R^-1 = U^T U with U = R^-1 = J L^-1 J, and a Cholesky factor with positive diagonal is unique.  In
+    fp32 this is at least as close to the exact U as the three-step chain (one rounding cascade less).  L^-1 comes
+    from the GEMM-based recursion `_cholinv_lower`."""
+    A = torch.flip(hessian, (0, 1)).contiguous()
+    Linv = torch.zeros_like(A)
+    _cholinv_lower(A, Linv)
+    return torch.flip(Linv, (0, 1)).contiguous()
+
+
+def prepare_hinv(hessian: torch.Tensor, damp_percent: float = 0.1):
+    """gptq.py:269-295 up to `hessian_inv`: dead columns, damping, U = chol_upper(H^-1).  `hessian` [K, K] fp32 is
+    modified in place like the reference does.  Returns (U, dead-column mask); Linears that read one activation
+    share both."""
+    assert hessian.ndim == 2 and hessian.dtype == torch.float32, "Hessian should be 2D fp32"
+    K = hessian.shape[0]
+    dead = torch.diag(hessian) == 0
+    idx = torch.arange(K, device=hessian.device)
+    hessian[idx[dead], idx[dead]] = 1
+    damp = damp_percent * torch.mean(torch.diag(hessian))
+    hessian[idx, idx] += damp
+    return _upper_cholesky_of_inverse(hessian), dead
 
 
 class GPTQ:

@@ -20,7 +20,7 @@ from typing import Dict, Iterator, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from nncf_amd import _lib
+from nncf_amd.gptq import HessianAccumulator
 from nncf_amd.statistics import WCTensorStatistic, activation_stats
 
 
@@ -116,35 +116,27 @@ class LayerwiseFeeder:
         self._cache = None
 
     def __iter__(self) -> Iterator[Tuple[List[str], torch.Tensor, WCTensorStatistic]]:
-        L = _lib.lib()
         try:
             for gi, group in enumerate(self._groups):
                 first = self._mods[group[0]]
                 k = first.in_features
-                H = torch.zeros((k, k), dtype=torch.float32, device=first.weight.device)
+                acc = HessianAccumulator(k, first.weight.device)
                 stats = WCTensorStatistic()
-                state = {"n": 0}
 
-                def pre(mod, args, kwargs, H=H, stats=stats, state=state, k=k):
+                def pre(mod, args, kwargs, acc=acc, stats=stats, k=k):
                     x = args[0] if args else next(iter(kwargs.values()))
                     if x.dtype == torch.float64:
                         x = x.float()
                     bs = x.shape[0] if x.ndim == 3 else 1  # gptq.py:226-235
-                    x2 = x.reshape(-1, k).contiguous()
-                    n = state["n"]
-                    beta = n / (n + bs)
-                    n += bs
-                    state["n"] = n
-                    with torch.cuda.device(x2.device):
-                        _lib.check(L.nncf_amd_hessian_accumulate(_lib.ptr(H), _lib.ptr(x2), _lib.dtype_id(x2), x2.shape[0],
-                                                                 k, 2.0 / n, beta, _lib.stream_of(x2)))
+                    x2 = x.reshape(-1, k)
+                    acc.add(x2, bs)  # buffered: ~32k tokens per MFMA SYRK launch
                     mean, _ = activation_stats(x2.reshape(1, -1, k), want_stats=False)
                     stats.mean_values.append(mean.to(x.dtype))
                     stats.shape_values.append(tuple(x.shape))
                     raise _EarlyExit
 
                 self._run(first, pre_hook=pre)
-                yield group, H, stats
+                yield group, acc.result(), stats
                 # the caller has replaced the weights of `group` by now; close the block if this was its last group
                 blk = self._block_of.get(group[0])
                 nxt = self._groups[gi + 1] if gi + 1 < len(self._groups) else None

@@ -587,18 +587,21 @@ class WeightCompression:
         by_name = {wp.module_name: wp for wp in targets}
         res: Dict[str, CompressedWeight] = {}
         for group, hessian, stats in feeder:
-            # every Linear of `group` reads the same activation: ONE Hessian (and one set of token means) serves all
-            for name in group:
-                wp = by_name[name]
-                cfg = wp.compression_config
-                if cfg.mode in INT8_MODES:
-                    continue
+            # every Linear of `group` reads the same activation: ONE Hessian, ONE Cholesky chain (and one set of token
+            # means) serve all of them
+            members = [by_name[name] for name in group if by_name[name].compression_config.mode not in INT8_MODES]
+            if not members:
+                continue
+            hinv, dead = gptq_mod.prepare_hinv(hessian, p.damp_percent)
+            del hessian
+            for wp in members:
                 weight = wp.module.weight.data
                 w32 = weight.to(torch.float32).contiguous()
                 if w32.data_ptr() == weight.data_ptr():
                     w32 = w32.clone()
-                q, scale, zp = gptq_mod.quantize_weights(hessian.clone(), w32, cfg, None, p.damp_percent, p.block_size,
-                                                         self._scale_estimation, wp.reduction_axes, input_stats=stats)
+                q, scale, zp = gptq_mod.quantize_weights(None, w32, wp.compression_config, None, p.damp_percent,
+                                                         p.block_size, self._scale_estimation, wp.reduction_axes,
+                                                         input_stats=stats, hinv=hinv, dead=dead)
                 wp.module.weight.data = q.to(weight.dtype)
                 res[wp.weight_name] = CompressedWeight(None, scale, zp, None)
         return res
