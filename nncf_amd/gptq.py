@@ -120,32 +120,44 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
     mode_id = _lib.MODE_ID[config.mode.value]
     L = _lib.lib()
     block_cfg = WeightCompressionConfig(mode=config.mode, group_size=-1)
+    # Trailing update (gptq.py:363), two levels: after each 128-column block the error goes into the rest of its
+    # SUPER-block only (k = 128 GEMM over <= 896 columns); the columns beyond get the errors of all eight blocks in
+    # ONE k = 1024 GEMM when the super-block is done.  Same sums, regrouped: the k = 128 update of the whole
+    # remainder streams W once per block (4 N K^2 / 128 bytes: 210 GB for 8192 x 28672), this form once per 1024.
+    super_cols = SUPER_BLOCKS * block_size
     with torch.cuda.device(W.device):
         stream = _lib.stream_of(W)
-        for i1 in range(0, K, block_size):
-            i2 = min(i1 + block_size, K)
-            count = i2 - i1
-            if use_se:
-                # gptq.py:319-327: parameters of every group that STARTS in this block, from the current W
-                for c in range(i1, i2):
-                    if c % gs:
-                        continue
-                    if input_stats is not None:
-                        stats = WCTensorStatistic([m[..., c:c + gs] for m in input_stats.mean_values],
-                                                  [tuple(sh[:-1]) + (gs,) for sh in input_stats.shape_values])
-                    else:
-                        acts = [inp[..., c:c + gs] for inp in inputs]
-                        stats = activations_to_wc_statistics(acts)
-                    sc, zp = se.calculate_quantization_params(stats, W[:, c:c + gs].contiguous(), (1,), block_cfg)
-                    scales[:, c // gs] = sc.reshape(N)
-                    if asym:
-                        zps[:, c // gs] = zp.reshape(N).to(torch.int32)
-            err = torch.empty((N, count), dtype=torch.float32, device=W.device)
-            st = L.nncf_amd_gptq_block(_lib.ptr(W), _lib.ptr(Q), _lib.ptr(err), _lib.ptr(hinv), N, K, i1, count, gs,
-                                       mode_id, _lib.ptr(scales), _lib.ptr(zps), int(use_se), stream)
-            _lib.check(st)
-            if i2 < K:
-                W[:, i2:] -= torch.matmul(err, hinv[i1:i2, i2:])  # gptq.py:363, plain library GEMM
+        for s1 in range(0, K, super_cols):
+            s2 = min(s1 + super_cols, K)
+            errs = torch.empty((N, s2 - s1), dtype=torch.float32, device=W.device) if s2 < K else None
+            for i1 in range(s1, s2, block_size):
+                i2 = min(i1 + block_size, s2)
+                count = i2 - i1
+                if use_se:
+                    # gptq.py:319-327: parameters of every group that STARTS in this block, from the current W
+                    for c in range(i1, i2):
+                        if c % gs:
+                            continue
+                        if input_stats is not None:
+                            stats = WCTensorStatistic([m[..., c:c + gs] for m in input_stats.mean_values],
+                                                      [tuple(sh[:-1]) + (gs,) for sh in input_stats.shape_values])
+                        else:
+                            acts = [inp[..., c:c + gs] for inp in inputs]
+                            stats = activations_to_wc_statistics(acts)
+                        sc, zp = se.calculate_quantization_params(stats, W[:, c:c + gs].contiguous(), (1,), block_cfg)
+                        scales[:, c // gs] = sc.reshape(N)
+                        if asym:
+                            zps[:, c // gs] = zp.reshape(N).to(torch.int32)
+                err = torch.empty((N, count), dtype=torch.float32, device=W.device)
+                st = L.nncf_amd_gptq_block(_lib.ptr(W), _lib.ptr(Q), _lib.ptr(err), _lib.ptr(hinv), N, K, i1, count, gs,
+                                           mode_id, _lib.ptr(scales), _lib.ptr(zps), int(use_se), stream)
+                _lib.check(st)
+                if i2 < s2:
+                    W[:, i2:s2].addmm_(err, hinv[i1:i2, i2:s2], alpha=-1.0)
+                if errs is not None:
+                    errs[:, i1 - s1:i2 - s1] = err
+            if errs is not None:
+                W[:, s2:].addmm_(errs, hinv[s1:s2, s2:], alpha=-1.0)
     out_scales = scales.reshape(N, ngroups, 1)
     out_zps = zps.reshape(N, ngroups, 1) if asym else None
     if config.group_size == -1:
@@ -155,6 +167,7 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
     return Q, out_scales, out_zps
 
 
+SUPER_BLOCKS = 8  # 128-column blocks per far trailing update (see quantize_weights)
 CHOLINV_BASE = 1024  # below this size the LAPACK-style routines (rocSOLVER potrf, rocBLAS trsm) are used directly
 
 
