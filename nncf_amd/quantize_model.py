@@ -478,17 +478,19 @@ class WeightCompression:
         backup = WeightCompressionConfig()  # INT8_ASYM per-channel
         eps = torch.finfo(torch.float32).eps
         metric = self._sensitivity_metric
+        # weight part of every score: all launches queued, one synchronisation
+        scored = [wp for wp in ratio_defining
+                  if not (metric != SensitivityMetric.WEIGHT_QUANTIZATION_ERROR and wp.kind == "embedding")]
+        reduction = "frobenius" if metric == SensitivityMetric.HESSIAN_INPUT_ACTIVATION else "max_mean"
+        errs = dict(zip((wp.weight_name for wp in scored), wl.get_integer_quantization_errors(
+            [wp.module.weight.data for wp in scored], [wp.reduction_axes for wp in scored], backup, reduction)))
         scores = []
         for wp in ratio_defining:
-            if metric != SensitivityMetric.WEIGHT_QUANTIZATION_ERROR and wp.kind == "embedding":
+            if wp.weight_name not in errs:
                 scores.append(THE_LOWEST_SENSITIVITY)
                 continue
-            w = wp.module.weight.data
-            if metric == SensitivityMetric.HESSIAN_INPUT_ACTIVATION:
-                weight_score = wl.get_integer_quantization_error(w, wp.reduction_axes, backup, reduction="frobenius")
-            else:
-                err = wl.get_integer_quantization_error(w, wp.reduction_axes, backup, reduction="max_mean")
-                weight_score = 1 / (err + eps)
+            err = errs[wp.weight_name]
+            weight_score = err if metric == SensitivityMetric.HESSIAN_INPUT_ACTIVATION else 1 / (err + eps)
             if metric == SensitivityMetric.WEIGHT_QUANTIZATION_ERROR:
                 scores.append(weight_score)
             else:
@@ -634,6 +636,11 @@ class WeightCompression:
         for wp in all_params:
             insert_decompressor(self._model, wp, results[wp.weight_name])
 
+    def _statistics_tag(self) -> str:
+        """What a statistics cache file must have been collected for to be reusable."""
+        return (f"subset={self._subset_size};mean={int(bool(self._data_aware_compression))};"
+                f"metric={self._sensitivity_metric.value if self._data_aware_mixed_precision else 'none'}")
+
     # ---- algorithm.py:1090-1232
     def apply(self, model: nn.Module, dataset: Optional[Dataset], example_input) -> nn.Module:
         self._model = model
@@ -642,7 +649,14 @@ class WeightCompression:
         statistics, activation_scores = None, {}
         if dataset is not None and (self._data_aware_mixed_precision or self._data_aware_compression):
             stat_params = ratio_defining if self._backup_mode == BackupMode.NONE else all_params
-            statistics, activation_scores = self.collect_statistics(model, dataset, trace, stat_params)
+            cache = self._adv.statistics_path
+            cached = load_statistics(cache, _model_device(model), self._statistics_tag()) if cache else None
+            if cached is not None:
+                statistics, activation_scores = cached
+            else:
+                statistics, activation_scores = self.collect_statistics(model, dataset, trace, stat_params)
+                if cache:
+                    save_statistics(cache, statistics, activation_scores, self._statistics_tag())
             statistics = statistics or None
         self.apply_mixed_precision(ratio_defining, activation_scores)
         self.validate_group_size(ratio_defining)
@@ -738,9 +752,6 @@ def compress_weights(model: nn.Module, *, mode=CompressWeightsMode.INT8_ASYM, ra
     if lora_correction is not None:
         msg = "Torch backend does not support lora_correction option(s). Set them to None."
         raise ParameterNotSupportedError(msg)
-    if advanced_parameters and advanced_parameters.statistics_path:
-        msg = "Torch backend does not support statistics caching."
-        raise ParameterNotSupportedError(msg)
     sensitivity_metric = None if sensitivity_metric is None else enum_of(SensitivityMetric, sensitivity_metric)
     backup_mode = None if backup_mode is None else enum_of(BackupMode, backup_mode)
     if dataset is None:
@@ -784,4 +795,129 @@ def compress_weights(model: nn.Module, *, mode=CompressWeightsMode.INT8_ASYM, ra
     finally:
         model.train(was_training)
     model._nncf_amd_weight_compression = algo.bitwidth_report
+    return model
+
+
+# ----------------------------------------------------------------------------- statistics cache
+def save_statistics(path: str, statistics: Dict[str, WCTensorStatistic], activation_scores: Dict[str, float],
+                    tag: str) -> None:
+    """The statistics of one calibration run as one safetensors file (the reference caches them per node as
+    safetensors too, common/tensor_statistics/statistics_serializer.py:81-148, but rejects `statistics_path` on its
+    Torch backend, quantize_model.py:527-529): AWQ / scale estimation / GPTQ / ratio sweeps over one model reuse
+    them instead of re-running the calibration forward passes."""
+    import json
+
+    from safetensors.torch import save_file
+
+    tensors, shapes = {}, {}
+    for name, st in (statistics or {}).items():
+        if st.mean_values:
+            tensors[name] = torch.stack([m.reshape(-1) for m in st.mean_values]).contiguous()
+            shapes[name] = [list(sh) for sh in st.shape_values]
+    if not tensors:
+        tensors["__empty__"] = torch.zeros(1)
+    save_file(tensors, path, metadata={"nncf_amd_statistics": json.dumps(
+        {"tag": tag, "shapes": shapes, "activation_scores": activation_scores})})
+
+
+def load_statistics(path: str, device, tag: str):
+    """(statistics, activation_scores) of `save_statistics`, or None if the file is absent or was collected for
+    other settings."""
+    import json
+    import os
+
+    from safetensors import safe_open
+
+    if not os.path.isfile(path):
+        return None
+    with safe_open(path, framework="pt", device=str(device)) as fh:
+        meta = json.loads(fh.metadata()["nncf_amd_statistics"])
+        if meta["tag"] != tag:
+            return None
+        statistics = {}
+        for name, shapes in meta["shapes"].items():
+            stacked = fh.get_tensor(name)
+            statistics[name] = WCTensorStatistic([stacked[i] for i in range(stacked.shape[0])],
+                                                 [tuple(sh) for sh in shapes])
+    return statistics, {k: float(v) for k, v in meta["activation_scores"].items()}
+
+
+# ------------------------------------------------------------------------------------ on-disk export (SURVEY 8 f4)
+_DTYPES = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16, "float64": torch.float64}
+
+
+def save_compressed(model: nn.Module, path: str) -> None:
+    """Writes the compressed model as ONE safetensors file: the model's state_dict (packed weights, fp16 / E8M0
+    scales, packed zero points, AWQ activation scales, everything left uncompressed) plus a JSON header that says
+    which module carries which decompressor.  The tensors are the reference's torch DQ storage format
+    (layers.py:1303-1460, quantize_functions.py:417-461: nibble pairs low-first, +8 bias for INT4_SYM)."""
+    import json
+
+    from safetensors.torch import save_file
+
+    entries, groups = {}, {}
+    for name, mod in model.named_modules():
+        if parametrize.is_parametrized(mod, "weight"):
+            plist = mod.parametrizations.weight
+            dec = plist[0]
+            e = {"decompressor": type(dec).__name__, "result_dtype": str(dec.result_dtype).replace("torch.", ""),
+                 "packed_shape": list(plist.original.shape)}
+            for attr in ("compressed_weight_shape", "result_shape", "zero_point_shape"):
+                if getattr(dec, attr, None) is not None:
+                    e[attr] = list(getattr(dec, attr))
+            first = groups.setdefault(id(plist.original), name)
+            if first != name:
+                e["shares_weight_with"] = first
+            entries[name] = e
+    sq = [name for name, mod in model.named_modules() if isinstance(getattr(mod, "awq_input_scale", None), SQMultiply)]
+    tensors, seen = {}, {}
+    for k, v in model.state_dict().items():
+        key = (v.data_ptr(), tuple(v.shape), v.dtype)
+        if v.numel() and key in seen:  # tied tensors are stored once (safetensors refuses shared storage)
+            continue
+        seen[key] = k
+        tensors[k] = v.detach().contiguous()
+    save_file(tensors, path, metadata={"nncf_amd_weight_compression": json.dumps({"weights": entries, "awq": sq})})
+
+
+def load_compressed(model: nn.Module, path: str) -> nn.Module:
+    """Turns a freshly built (uncompressed) `model` on the GPU into the compressed model stored by
+    `save_compressed`: installs the decompressors named in the header, then loads every tensor."""
+    import json
+
+    from safetensors import safe_open
+
+    device = _model_device(model)
+    with safe_open(path, framework="pt", device=str(device)) as fh:
+        header = json.loads(fh.metadata()["nncf_amd_weight_compression"])
+        tensors = {k: fh.get_tensor(k) for k in fh.keys()}
+    mods = dict(model.named_modules())
+    made: Dict[str, Tuple[nn.Parameter, nn.Module]] = {}
+    for name, e in header["weights"].items():
+        mod = mods[name]
+        src = e.get("shares_weight_with")
+        if src is not None:
+            packed, dec = made[src]
+        else:
+            prefix = f"{name}.parametrizations.weight."
+            cls = getattr(dcmp, e["decompressor"])
+            dec = cls.__new__(cls)
+            nn.Module.__init__(dec)
+            dec.register_buffer("_scale", tensors[prefix + "0._scale"])
+            if prefix + "0._zero_point" in tensors:
+                dec.register_buffer("_zero_point", tensors[prefix + "0._zero_point"])
+            dec.result_dtype = _DTYPES[e["result_dtype"]]
+            for attr in ("compressed_weight_shape", "result_shape", "zero_point_shape"):
+                if attr in e:
+                    setattr(dec, attr, tuple(e[attr]))
+            packed = nn.Parameter(tensors[prefix + "original"], requires_grad=False)
+            made[name] = (packed, dec)
+        mod.weight = packed
+        parametrize.register_parametrization(mod, "weight", dec, unsafe=True)
+    for name in header["awq"]:
+        insert_sq_multiply(mods[name], tensors[f"{name}.awq_input_scale._scale_value"])
+    missing, unexpected = model.load_state_dict(tensors, strict=False)
+    if unexpected:
+        raise InternalError(f"load_compressed: tensors without a place in the model: {unexpected[:5]}")
+    model.requires_grad_(False)
     return model

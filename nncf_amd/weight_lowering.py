@@ -234,9 +234,10 @@ def integer_quantize_dequantize_weight(weight: torch.Tensor, config: WeightCompr
     return dq
 
 
-def get_integer_quantization_error(weight: torch.Tensor, reduction_axes: ReductionAxes,
-                                   config: WeightCompressionConfig, reduction: str) -> float:
-    """weight_lowering.py:329-374."""
+def _queue_quantization_error(weight: torch.Tensor, reduction_axes: ReductionAxes, config: WeightCompressionConfig,
+                              reduction: str, res: torch.Tensor):
+    """Queues the error metric of one weight into the 1-element device tensor `res` (no synchronisation).  Returns
+    what must stay alive until the stream has run."""
     if reduction not in ["max_mean", "frobenius"]:
         exception_str = f"Unsupported aggregation mode: {reduction}."
         raise InternalError(exception_str)
@@ -250,13 +251,35 @@ def get_integer_quantization_error(weight: torch.Tensor, reduction_axes: Reducti
     L = _lib.lib()
     ws_bytes = L.nncf_amd_int_quant_error_workspace(outer, inner)
     ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=weight.device)
-    res = torch.empty(1, dtype=torch.float32, device=weight.device)
     with torch.cuda.device(weight.device):
         st = L.nncf_amd_int_quant_error(_lib.ptr(weight), _lib.dtype_id(weight), outer, r, inner, config.group_size,
                                         _lib.MODE_ID[config.mode.value], 0 if reduction == "max_mean" else 1,
                                         _lib.ptr(res), _lib.ptr(ws), ws_bytes, _lib.stream_of(weight))
     _lib.check(st)
+    return weight, ws
+
+
+def get_integer_quantization_error(weight: torch.Tensor, reduction_axes: ReductionAxes,
+                                   config: WeightCompressionConfig, reduction: str) -> float:
+    """weight_lowering.py:329-374."""
+    res = torch.empty(1, dtype=torch.float32, device=weight.device)
+    keep = _queue_quantization_error(weight, reduction_axes, config, reduction, res)  # noqa: F841
     return res.item()
+
+
+def get_integer_quantization_errors(weights, reduction_axes_list, config: WeightCompressionConfig,
+                                    reduction: str):
+    """The error metric of MANY weights (the mixed-precision scoring loop, mixed_precision.py:189-199) with every
+    launch queued back to back and ONE device synchronisation at the end, instead of one `.item()` per weight."""
+    weights = list(weights)
+    if not weights:
+        return []
+    res = torch.empty(len(weights), dtype=torch.float32, device=weights[0].device)
+    keep = [_queue_quantization_error(w, axes, config, reduction, res[i:i + 1])
+            for i, (w, axes) in enumerate(zip(weights, reduction_axes_list))]
+    out = res.tolist()
+    del keep
+    return out
 
 
 # ------------------------------------------------------------------ packing (torch/quantization/quantize_functions.py:417-473)

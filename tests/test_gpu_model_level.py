@@ -259,3 +259,51 @@ def test_tiny_lm_gptq(se):
         torch.testing.assert_close(h1, h2, rtol=1e-5, atol=1e-7, msg=str(g))
         for a, b in zip(s1.mean_values, s2.mean_values):
             torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["int4_asym_g32_r08_awq_se", "int8_asym_tied", "int4_sym_g32"])
+def test_save_and_load_compressed(name, tmp_path):
+    """On-disk export: safetensors round trip into a freshly built model gives the same tensors and the
+    same logits bit for bit."""
+    from nncf_amd.quantize_model import load_compressed, save_compressed
+
+    model, per, logits = _run_tiny(name)
+    path = str(tmp_path / "m.safetensors")
+    save_compressed(model, path)
+    mkw, _ = TINY_CONFIGS[name]
+    fresh = make_tiny_lm(seed=7, **mkw).cuda()
+    load_compressed(fresh, path)
+    sd1, sd2 = model.state_dict(), fresh.state_dict()
+    assert sorted(sd1) == sorted(sd2)
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), k
+    with torch.no_grad():
+        again = fresh(tiny_lm_dataset()[0].cuda()).float().cpu().numpy()
+    assert np.array_equal(again, logits)
+
+
+def test_statistics_cache_is_reused(tmp_path):
+    """with `statistics_path` the calibration statistics are written once and a second compression
+    (here: another algorithm mix over the same statistics) does not run the calibration set again."""
+    import nncf_amd
+    from nncf_amd.parameters import AdvancedCompressionParameters
+
+    path = str(tmp_path / "stats.safetensors")
+    adv = AdvancedCompressionParameters(statistics_path=path)
+    samples = tiny_lm_dataset()
+    m1 = make_tiny_lm().cuda()
+    nncf_amd.compress_weights(m1, mode="int4_asym", group_size=32, scale_estimation=True,
+                              dataset=nncf_amd.Dataset(samples), advanced_parameters=adv)
+    assert os.path.isfile(path)
+
+    class OnlyFirst:
+        """Yields the tracing sample; touching a second item means the statistics were collected again."""
+        def __iter__(self):
+            yield samples[0]
+            raise AssertionError("calibration data was read although a statistics cache exists")
+
+    m2 = make_tiny_lm().cuda()
+    nncf_amd.compress_weights(m2, mode="int4_asym", group_size=32, scale_estimation=True,
+                              dataset=nncf_amd.Dataset(OnlyFirst()), advanced_parameters=adv)
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1

@@ -95,16 +95,16 @@ def test_ratio_selection_walks_scores_in_ascending_order():
     _, ratio_defining, _ = algo.get_weight_compression_parameters(m, trace)
     scores = {wp.module_name: float(i) for i, wp in enumerate(ratio_defining)}
 
-    def fake_err(w, axes, cfg, reduction="max_mean"):
-        return 0.0
+    def fake_errs(ws, axes, cfg, reduction="max_mean"):
+        return [0.0] * len(ws)
 
-    orig = qm.wl.get_integer_quantization_error
-    qm.wl.get_integer_quantization_error = fake_err
+    orig = qm.wl.get_integer_quantization_errors
+    qm.wl.get_integer_quantization_errors = fake_errs
     try:
         algo._sensitivity_metric = SensitivityMetric.MAX_ACTIVATION_VARIANCE
         algo.apply_mixed_precision(ratio_defining, scores)
     finally:
-        qm.wl.get_integer_quantization_error = orig
+        qm.wl.get_integer_quantization_errors = orig
     total = sum(wp.num_weights for wp in ratio_defining)
     acc, want4 = 0, []
     for wp in ratio_defining:  # scores ascend with the index
@@ -199,3 +199,20 @@ def test_insert_decompressor_shares_tied_weights():
     assert m.lm_head.weight.dtype == torch.float32 and float(m.lm_head.weight[0, 0]) == 0.5
     out = m(tiny_lm_dataset()[0])
     assert out.shape == (1, 12, 160)
+
+
+def test_statistics_cache_round_trip(tmp_path):
+    from nncf_amd.statistics import WCTensorStatistic
+
+    stats = {"a.b": WCTensorStatistic([torch.arange(8.0), torch.arange(8.0) * 2], [(1, 12, 8), (1, 13, 8)]),
+             "c": WCTensorStatistic([torch.ones(4, dtype=torch.bfloat16)], [(2, 3, 4)])}
+    scores = {"a.b": 1.5, "c": 0.25}
+    path = str(tmp_path / "stats.safetensors")
+    qm.save_statistics(path, stats, scores, "tag1")
+    assert qm.load_statistics(path, "cpu", "other") is None
+    assert qm.load_statistics(str(tmp_path / "absent"), "cpu", "tag1") is None
+    got, got_scores = qm.load_statistics(path, "cpu", "tag1")
+    assert got_scores == scores and sorted(got) == ["a.b", "c"]
+    assert got["a.b"].shape_values == [(1, 12, 8), (1, 13, 8)]
+    assert torch.equal(got["a.b"].mean_values[1], torch.arange(8.0) * 2)
+    assert got["c"].mean_values[0].dtype == torch.bfloat16
