@@ -21,7 +21,7 @@ from collections import OrderedDict
 from dataclasses import dataclass, replace
 from functools import reduce
 from operator import mul
-from typing import Any, Dict, Iterable, List, Optional, Tuple
+from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -33,8 +33,8 @@ from nncf_amd import gptq as gptq_mod
 from nncf_amd import scale_estimation as se_mod
 from nncf_amd import weight_lowering as wl
 from nncf_amd import _lib
-from nncf_amd.errors import (InternalError, InvalidGroupSizeError, ParameterNotSupportedError, UnsupportedModelError,
-                             ValidationError)
+from nncf_amd.errors import (InternalError, InvalidGroupSizeError, ParameterNotSupportedError,
+                             UnsupportedBackendError, ValidationError)
 from nncf_amd.parameters import (AdvancedCompressionParameters, BackupMode, CompressedWeight, CompressWeightsMode,
                                  Dataset, GroupSizeFallbackMode, IgnoredScope, SensitivityMetric,
                                  WeightCompressionConfig, _mode_of, enum_of)
@@ -761,8 +761,6 @@ def compress_weights(model: nn.Module, *, mode=CompressWeightsMode.INT8_ASYM, ra
         dataset = Dataset(dataset)
     device = _model_device(model)
     if device.type != "cuda":
-        from nncf_amd.errors import UnsupportedBackendError
-
         raise UnsupportedBackendError("nncf_amd.compress_weights needs the model on an AMD GPU ('cuda' device); "
                                       "there is no CPU path in this build.")
     _lib.lib()  # a missing HIP library fails here, loudly

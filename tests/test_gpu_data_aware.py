@@ -224,6 +224,7 @@ def test_hessian_chunking_equals_item_by_item():
     acc = G.HessianAccumulator(256, xs[0].device, chunk_tokens=1)  # flushes after every item
     for x in xs:
         acc.add(x.reshape(-1, 256), 1)
-    torch.testing.assert_close(H, acc.result(), rtol=1e-5, atol=1e-6)
+    scale = float(H.abs().max())  # entries are sums with cancellation: errors scale with the diagonal
+    torch.testing.assert_close(H, acc.result(), rtol=1e-5, atol=1e-6 * scale)
     ref = sum(x[0].double().T @ x[0].double() for x in xs) * 2 / len(xs)
-    torch.testing.assert_close(H.double(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(H.double(), ref, rtol=1e-5, atol=1e-6 * scale)

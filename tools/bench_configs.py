@@ -95,6 +95,11 @@ def c4(args):
     W = {n: (torch.randn(s, device="cuda", generator=g) * 0.02).to(torch.bfloat16) for n, s in shapes.items()}
     ph = Phases()
     flops = 0.0
+    warm = torch.randn(2048, 2048, device="cuda")
+    gptq.prepare_hinv(warm.T @ warm / 2048, 0.1)  # library initialisation (rocSOLVER / hipBLASLt) stays untimed
+    gptq.quantize_weights(None, torch.randn(256, 2048, device="cuda"), cfg,
+                          hinv=gptq.prepare_hinv(warm.T @ warm / 2048, 0.1)[0], dead=torch.zeros(2048, dtype=torch.bool, device="cuda"))
+    del warm
     for key, k, names in groups:
         acts = make_acts(args.samples, args.tokens, k, outliers=False)
         gptq.calculate_hessian(acts[:2])  # warm-up (kernel load)
