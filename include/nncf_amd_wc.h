@@ -182,6 +182,17 @@ int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype, int64_t to
                                 float beta, void* stream);
 
 /*
+ * The same accumulation for a STREAM of calibration chunks (the sample loop of GPTQ._calculate_hessian,
+ * gptq.py:225-240): `_upper` updates only the upper triangle of H (no symmetrising pass per chunk; with beta = 1 no
+ * scaling pass either), `nncf_amd_hessian_finalize` multiplies H by `scale` and writes the lower triangle from the
+ * upper one.  Raw sums with alpha = beta = 1 and one finalize(scale = 2 / n) give the reference's running average
+ * (it telescopes to (2 / n) * sum X^T X).
+ */
+int nncf_amd_hessian_accumulate_upper(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k, float alpha,
+                                      float beta, void* stream);
+int nncf_amd_hessian_finalize(float* h, int64_t k, float scale, void* stream);
+
+/*
  * Fused inner step of scale estimation (ScaleEstimation.calculate_quantization_params,
  * src/nncf/quantization/algorithms/weight_compression/scale_estimation.py:300-360; get_target_zero_mask :380-393,
  * estimate_scales :396-409): quantize every group with the candidate `scale` (and `zero_point`, fp32 as scale

@@ -507,8 +507,39 @@ static int mirror(float* h, int64_t k, hipStream_t s) {
 
 }  // namespace wc
 
+static int hessian_accumulate_impl(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k, float alpha,
+                                   float beta, void* stream, bool do_mirror);
+
 extern "C" int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k, float alpha,
                                            float beta, void* stream) {
+    return hessian_accumulate_impl(h, x, x_dtype, tokens, k, alpha, beta, stream, true);
+}
+
+extern "C" int nncf_amd_hessian_accumulate_upper(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k,
+                                                 float alpha, float beta, void* stream) {
+    return hessian_accumulate_impl(h, x, x_dtype, tokens, k, alpha, beta, stream, false);
+}
+
+extern "C" int nncf_amd_hessian_finalize(float* h, int64_t k, float scale, void* stream) {
+    using namespace wc;
+    if (!h || k <= 0) {
+        set_error("hessian_finalize: bad argument (k=%lld)", (long long)k);
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (scale != 1.0f) {
+        const int64_t n = k * k;
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_scale_matrix, dim3((unsigned)blocks), dim3(256), 0, s, h, n, scale);
+        int st = launch_status("hessian_scale");
+        if (st != NNCF_AMD_OK) return st;
+    }
+    return mirror(h, k, s);
+}
+
+static int hessian_accumulate_impl(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k, float alpha,
+                                   float beta, void* stream, bool do_mirror) {
     using namespace wc;
     if (!h || k <= 0 || tokens < 0 || (tokens > 0 && !x)) {
         set_error("hessian_accumulate: bad argument (k=%lld tokens=%lld)", (long long)k, (long long)tokens);
@@ -566,7 +597,7 @@ extern "C" int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype,
                 hipLaunchKernelGGL((k_syrk16b<NNCF_AMD_F16>), g16, dim3(256), lds_bytes, s, h, x, tokens, k, alpha, nt, rps);
             int st16 = launch_status("hessian_syrk16b");
             if (st16 != NNCF_AMD_OK) return st16;
-            return mirror(h, k, s);
+            return do_mirror ? mirror(h, k, s) : NNCF_AMD_OK;
         }
         if (x_dtype == NNCF_AMD_BF16)
             hipLaunchKernelGGL((k_syrk16<NNCF_AMD_BF16>), g16, dim3(256), 0, s, h, x, tokens, k, alpha, nt, rps);
@@ -574,7 +605,7 @@ extern "C" int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype,
             hipLaunchKernelGGL((k_syrk16<NNCF_AMD_F16>), g16, dim3(256), 0, s, h, x, tokens, k, alpha, nt, rps);
         int st16 = launch_status("hessian_syrk16");
         if (st16 != NNCF_AMD_OK) return st16;
-        return mirror(h, k, s);
+        return do_mirror ? mirror(h, k, s) : NNCF_AMD_OK;
     }
 #define LAUNCH(DT)                                                                                                      \
     if (vec)                                                                                                            \
@@ -592,5 +623,5 @@ extern "C" int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype,
 #undef LAUNCH
     int st32 = launch_status("hessian_syrk");
     if (st32 != NNCF_AMD_OK) return st32;
-    return mirror(h, k, s);
+    return do_mirror ? mirror(h, k, s) : NNCF_AMD_OK;
 }

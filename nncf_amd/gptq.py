@@ -27,18 +27,21 @@ HESSIAN_CHUNK_BYTES = 1 << 30
 
 class HessianAccumulator:
     """Running average of gptq.py:237-240, `H <- H n/(n+b) + (2/(n+b)) X^T X`, for a stream of calibration items.
-    Items are buffered and concatenated into chunks of ~32k tokens per SYRK launch: by induction the chunked update
-    with b = sum of the items' batch sizes equals the item-by-item recursion exactly (as real arithmetic), and one
-    long launch runs the MFMA kernel at 3x the rate of sixteen 2048-token ones."""
+    The recursion telescopes to H = (2/n) sum X^T X (as real arithmetic), so the raw sums are accumulated and
+    scaled once.  Items are buffered and concatenated into chunks of ~32k tokens per SYRK launch: one long launch
+    runs the MFMA kernel at 3x the rate of sixteen 2048-token ones."""
 
     def __init__(self, k: int, device, chunk_tokens: int = HESSIAN_CHUNK_TOKENS):
         self.k, self.nsamples, self._chunk_tokens = k, 0, chunk_tokens
         self.H = torch.zeros((k, k), dtype=torch.float32, device=device)
         self._buf: List[torch.Tensor] = []
         self._buf_tokens = self._buf_bs = 0
+        self._final = False
 
     def add(self, x2d: torch.Tensor, batch_size: int) -> None:
         """x2d [tokens, K] (any float dtype the kernel takes); batch_size = the item's contribution to n."""
+        if self._final:
+            raise RuntimeError("HessianAccumulator: result() was already taken")
         if self._buf and self._buf[0].dtype != x2d.dtype:
             self.flush()
         self._buf.append(x2d)
@@ -49,22 +52,29 @@ class HessianAccumulator:
             self.flush()
 
     def flush(self) -> None:
+        """Adds the buffered items' raw X^T X to the upper triangle of H (alpha = beta = 1: no scaling pass and no
+        symmetrising pass per chunk; `result` scales by 2 / n and mirrors once)."""
         if not self._buf:
             return
         x = self._buf[0] if len(self._buf) == 1 else torch.cat(self._buf, dim=0)
         x = x.contiguous()
-        n, bs = self.nsamples, self._buf_bs
-        beta = n / (n + bs)
-        self.nsamples = n + bs
-        alpha = 2.0 / self.nsamples
+        self.nsamples += self._buf_bs
         with torch.cuda.device(x.device):
-            st = _lib.lib().nncf_amd_hessian_accumulate(_lib.ptr(self.H), _lib.ptr(x), _lib.dtype_id(x), x.shape[0],
-                                                        self.k, alpha, beta, _lib.stream_of(x))
+            st = _lib.lib().nncf_amd_hessian_accumulate_upper(_lib.ptr(self.H), _lib.ptr(x), _lib.dtype_id(x),
+                                                              x.shape[0], self.k, 1.0, 1.0, _lib.stream_of(x))
         _lib.check(st)
         self._buf, self._buf_tokens, self._buf_bs = [], 0, 0
+        self._final = False
 
     def result(self) -> torch.Tensor:
+        """H = (2 / n) sum X^T X, symmetric.  The accumulator is finished by this call."""
         self.flush()
+        if not self._final and self.nsamples > 0:
+            with torch.cuda.device(self.H.device):
+                st = _lib.lib().nncf_amd_hessian_finalize(_lib.ptr(self.H), self.k, 2.0 / self.nsamples,
+                                                          _lib.stream_of(self.H))
+            _lib.check(st)
+            self._final = True
         return self.H
 
 

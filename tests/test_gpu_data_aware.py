@@ -54,7 +54,8 @@ def test_golden_hessian(golden):
     xs = [torch.from_numpy(x).cuda() for x in g["xs"]]
     H = gptq.calculate_hessian(xs)
     assert tuple(H.shape) == g["H_torch"].shape
-    np.testing.assert_allclose(host(H), g["H_torch"], rtol=1e-5, atol=1e-6)
+    # entries are sums with cancellation: the error scales with the diagonal (fp32 eps x |H|max), not with the entry
+    np.testing.assert_allclose(host(H), g["H_torch"], rtol=1e-5, atol=1e-6 * np.abs(g["H_torch"]).max())
     assert np.array_equal(host(H)[0], host(H)[0].T)  # written symmetric by construction
 
 
