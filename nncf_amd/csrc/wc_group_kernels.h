@@ -223,6 +223,9 @@ constexpr int kMaxBatch = 48;
 #define WC_GROUPS 32
 #endif
 constexpr int kClaimGroupsUsed = WC_GROUPS;
+constexpr int kClaimChunk = 3;       // tiles handed out per claim by the multi-tensor tile kernel
+constexpr int kTileClaimGroups = 8;  // parts (sequential streams) of its tile range
+constexpr int kTileBlocksPerCU = 3;  // resident blocks per CU it is launched with
 constexpr int kClaimSlots = 32, kClaimGroups = 128, kClaimStride = 32, kClaimDevices = 16;
 constexpr int kBatchGrid = 2048;  // 256 CUs x 8 blocks; the resident waves stride over the rest
 struct BatchArgs {
@@ -237,6 +240,7 @@ struct BatchArgs {
     void* aux[kMaxBatch];  // int32 zero points (asymmetric integer modes) or uint8 E8M0 scales (MXFP4); may be NULL
     uint32_t* ctr;                  // claim counters of this launch's slot (kClaimStride words apart)
     uint32_t log2_groups;           // claim groups of this launch = 1 << log2_groups (<= grid)
+    uint32_t chunk;                 // tiles per claim (k_grouped_batch; 1 for the row kernels' units)
     uint32_t base[kClaimGroups];    // value of each counter when the launch starts
     uint32_t part_lo[kClaimGroups + 1];  // tile range of each part (proportional to the blocks serving it)
 };
@@ -364,12 +368,14 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     const uint32_t part = (blockIdx.x >> 3) & ((1u << b.log2_groups) - 1);
     const uint32_t lo = b.part_lo[part], hi = b.part_lo[part + 1];
     uint32_t* ctr = b.ctr + part * kClaimStride;
-    const uint32_t cbase = lo - b.base[part];  // tile = cbase + claimed value (mod 2^32)
+    // a claim hands out `chunk` consecutive tiles: claimed value v -> tiles lo + (v - base) * chunk ... (mod 2^32)
+    const uint32_t cbase = b.base[part], chunk = b.chunk;
     uint32_t claim = 0;
     if (lane == 0) claim = claim_async(ctr);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
-    uint32_t t = cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+    uint32_t t = lo + ((uint32_t)__builtin_amdgcn_readfirstlane((int)claim) - cbase) * chunk;
     if (t >= hi) return;  // (a wave makes exactly one failing claim: the host's running counter values rely on it)
+    uint32_t cend = t + chunk < hi ? t + chunk : hi;  // end of the chunk being worked on
 #ifdef WC_CLK  // developer build: per-wave start/end times into scale[0] (read back by tools/kbench.hip, WC_CLK=<file>)
     const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     while (t >= b.tile_start[i + 1]) ++i;
     Desc cur = load_desc(i);
     issue_dma(t, cur);
-    // claim of the tile after this one: in flight together with the DMA, both waited for at the loop top
+    // claim of the chunk after this one: in flight together with the DMA, both waited for at the loop top
     if (lane == 0) claim = claim_async(ctr);
     uint32_t pend[NW];
     uint8_t* pend_dst = nullptr;  // per lane; NULL = nothing pending
@@ -390,7 +396,9 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
             unpack<DT>(raw, f + k * E);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const uint32_t tn = cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+        uint32_t tn = t + 1;
+        const bool new_chunk = tn >= cend;  // wave-uniform
+        if (new_chunk) tn = lo + ((uint32_t)__builtin_amdgcn_readfirstlane((int)claim) - cbase) * chunk;
         Desc nxt = cur;
         if (tn < hi) {
             if (tn >= nxt.end) {
@@ -398,7 +406,10 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
                 nxt = load_desc(i);
             }
             issue_dma(tn, nxt);
-            if (lane == 0) claim = claim_async(ctr);
+            if (new_chunk) {
+                cend = tn + chunk < hi ? tn + chunk : hi;
+                if (lane == 0) claim = claim_async(ctr);
+            }
         }
         if (pend_dst) store_packed(pend_dst, pend);
         const uint32_t lt = t - cur.start;
@@ -442,12 +453,13 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
 
 // blocks of `kernel` the device holds at once (cached by the caller per kernel instantiation)
 template <typename Kernel>
-static int resident_blocks(Kernel kernel) {
+static int resident_blocks(Kernel kernel, int max_per_cu = 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess ||
         hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
         return kBatchGrid;
+    if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;
     return per_cu * prop.multiProcessorCount;
 }
 
@@ -455,7 +467,8 @@ static int resident_blocks(Kernel kernel) {
 // the parts and the counters' current values, launches, and advances the host's copy of the counters (every team
 // stops at its first failed claim, so a launch adds units-in-part + teams-on-part to each counter).
 template <typename Kernel>
-static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block, BatchArgs& b, hipStream_t s) {
+static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block, BatchArgs& b, hipStream_t s,
+                                 uint32_t chunk = 1, int groups_used = kClaimGroupsUsed) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -466,7 +479,7 @@ static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block,
     const uint32_t units = b.tile_start[b.n];
     if (blocks < 1) return hipSuccess;
     int lg = 0;
-    while ((16 << lg) <= blocks && (2 << lg) <= kClaimGroupsUsed) ++lg;  // at least one octet of blocks per part
+    while ((16 << lg) <= blocks && (2 << lg) <= groups_used) ++lg;  // at least one octet of blocks per part
     const int groups = 1 << lg;
     uint32_t blocks_on[kClaimGroups] = {};
     for (int x = 0; x < blocks; ++x) ++blocks_on[(x >> 3) & (groups - 1)];
@@ -475,6 +488,7 @@ static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block,
     uint32_t* shadow = g_claim_host[dev][slot];
     b.ctr = sym + (size_t)slot * kClaimGroups * kClaimStride;
     b.log2_groups = (uint32_t)lg;
+    b.chunk = chunk;
     uint32_t seen = 0;
     for (int g = 0; g < groups; ++g) {
         b.base[g] = shadow[g];
@@ -486,17 +500,36 @@ static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block,
     e = hipPeekAtLastError();
     if (e != hipSuccess) return e;
     for (int g = 0; g < groups; ++g)
-        shadow[g] += (b.part_lo[g + 1] - b.part_lo[g]) + (uint32_t)teams_per_block * blocks_on[g];
+        shadow[g] += (b.part_lo[g + 1] - b.part_lo[g] + chunk - 1) / chunk + (uint32_t)teams_per_block * blocks_on[g];
     return hipSuccess;
 }
 
 // grid of a multi-tensor launch: one resident set of blocks (never a second, under-occupied round), at most one
 // wave per tile.
+// developer knobs of the tile kernel's launch shape (environment, read once); defaults = the measured optimum
+static int tile_knob(const char* name, int lo, int hi, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return (v >= lo && v <= hi) ? v : dflt;
+}
+
 template <typename Policy, int DT, int VPG>
 static hipError_t launch_batch_kernel(BatchArgs& b, hipStream_t s) {
-    static const int resident = resident_blocks(k_grouped_batch<Policy, DT, VPG>);
+    // Measured on MI355X (bench.py, Llama-3-8B INT4_SYM g128; the other modes move the same way): the HBM system
+    // saturates at 3 blocks (12 waves, 48 KiB of tiles in flight) per CU -- 1: 0.31, 2: 0.59, 3: 0.69, 4: 0.68,
+    // 6 (occupancy limit): 0.67 of the roofline -- and likes FEW sequential streams: 64 parts 0.66, 32: 0.69,
+    // 16: 0.70; below that one counter per part runs into the ~10^8 atomics/s an address sustains (8 parts: 0.42),
+    // so a claim hands out kClaimChunk consecutive tiles: 8 parts x 3 tiles 0.71.
+    static const int per_cu = tile_knob("NNCF_AMD_BLOCKS_PER_CU", 1, 16, kTileBlocksPerCU);
+    static const int resident = resident_blocks(k_grouped_batch<Policy, DT, VPG>, per_cu);
+    static const uint32_t chunk = (uint32_t)tile_knob("NNCF_AMD_CLAIM_CHUNK", 1, 64, kClaimChunk);
+    static const int groups = [] {
+        const int v = tile_knob("NNCF_AMD_CLAIM_GROUPS", 1, kClaimGroups, kTileClaimGroups);
+        return (v & (v - 1)) == 0 ? v : kTileClaimGroups;
+    }();
     const int64_t blocks = ((int64_t)b.tile_start[b.n] + 3) / 4;
-    return launch_claimed(k_grouped_batch<Policy, DT, VPG>, (int)(blocks < resident ? blocks : resident), 4, b, s);
+    return launch_claimed(k_grouped_batch<Policy, DT, VPG>, (int)(blocks < resident ? blocks : resident), 4, b, s, chunk,
+                          groups);
 }
 
 template <typename Policy, int DT, int VPG>

@@ -477,7 +477,8 @@ __global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const vo
 // H[j][i] = H[i][j] for i < j: the SYRK kernels accumulate the upper triangle only, so H comes out exactly
 // symmetric whatever the order of the atomic partial sums.  64x64 tiles transposed through LDS: reads and writes
 // are row-contiguous.
-__global__ __launch_bounds__(256) void k_mirror_upper(float* __restrict__ h, uint32_t K) {
+// `scale` != 1 (finalize of a stream of raw sums): the upper triangle is multiplied in the same pass.
+__global__ __launch_bounds__(256) void k_mirror_upper(float* __restrict__ h, uint32_t K, float scale) {
     __shared__ float t[64][65];
     const uint32_t nt = (K + 63) / 64;
     uint32_t p = blockIdx.x, bi = 0;  // (bi <= bj) from blockIdx.x
@@ -490,7 +491,15 @@ __global__ __launch_bounds__(256) void k_mirror_upper(float* __restrict__ h, uin
     const uint32_t c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
     for (uint32_t r = r4; r < 64; r += 4) {
         const uint32_t gi = i0 + r, gj = j0 + c;
-        t[r][c] = (gi < K && gj < K) ? h[(size_t)gi * K + gj] : 0.0f;
+        float v = 0.0f;
+        if (gi < K && gj < K) {
+            v = h[(size_t)gi * K + gj];
+            if (scale != 1.0f && gi <= gj) {
+                v *= scale;
+                h[(size_t)gi * K + gj] = v;
+            }
+        }
+        t[r][c] = v;
     }
     __syncthreads();
     for (uint32_t r = r4; r < 64; r += 4) {
@@ -499,9 +508,9 @@ __global__ __launch_bounds__(256) void k_mirror_upper(float* __restrict__ h, uin
     }
 }
 
-static int mirror(float* h, int64_t k, hipStream_t s) {
+static int mirror(float* h, int64_t k, hipStream_t s, float scale = 1.0f) {
     const uint32_t mt = (uint32_t)((k + 63) / 64);
-    hipLaunchKernelGGL(k_mirror_upper, dim3(mt * (mt + 1) / 2), dim3(256), 0, s, h, (uint32_t)k);
+    hipLaunchKernelGGL(k_mirror_upper, dim3(mt * (mt + 1) / 2), dim3(256), 0, s, h, (uint32_t)k, scale);
     return launch_status("hessian_mirror");
 }
 
@@ -526,16 +535,7 @@ extern "C" int nncf_amd_hessian_finalize(float* h, int64_t k, float scale, void*
         set_error("hessian_finalize: bad argument (k=%lld)", (long long)k);
         return NNCF_AMD_ERR_BAD_ARG;
     }
-    hipStream_t s = (hipStream_t)stream;
-    if (scale != 1.0f) {
-        const int64_t n = k * k;
-        int64_t blocks = (n + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(k_scale_matrix, dim3((unsigned)blocks), dim3(256), 0, s, h, n, scale);
-        int st = launch_status("hessian_scale");
-        if (st != NNCF_AMD_OK) return st;
-    }
-    return mirror(h, k, s);
+    return mirror(h, k, (hipStream_t)stream, scale);  // scales the upper triangle and writes the lower one in one pass
 }
 
 static int hessian_accumulate_impl(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k, float alpha,

@@ -230,12 +230,26 @@ static inline RowClass row_class(int64_t vpr) {
     return {0, 0};
 }
 
+constexpr int kRowBlocksPerCU = 0;  // 0: as many as fit (occupancy)
+
 template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED>
 static hipError_t launch_rows(BatchArgs& b, hipStream_t s) {
-    static const int resident = resident_blocks(k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>);
+    static const int per_cu = tile_knob("NNCF_AMD_ROW_BLOCKS_PER_CU", 1, 16, kRowBlocksPerCU);
+    static const int resident = resident_blocks(k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>, per_cu);
+    // Parts of the row range (sequential streams): as few as the claim counters allow -- measured on Llama-3-8B INT8
+    // (8 KiB and 28 KiB rows): 32 parts 0.63, 16: 0.66, 8: 0.68 of the roofline, 4: 0.52 (one address sustains ~10^8
+    // atomics/s) -- so the count follows the shortest row of the launch: ~6 x 10^7 claims/s per counter at the
+    // ~3.6 TB/s the rows are read with.
+    static const int forced = tile_knob("NNCF_AMD_ROW_CLAIM_GROUPS", 1, kClaimGroups, 0);
+    uint32_t min_vpr = 0xffffffffu;
+    for (int j = 0; j < b.n; ++j) min_vpr = b.nfull[j] < min_vpr ? b.nfull[j] : min_vpr;
+    int groups = 8;
+    while (groups < kClaimGroupsUsed && (double)groups * (double)min_vpr * 16.0 * 6e7 < 3.6e12) groups *= 2;
+    if (forced > 0 && (forced & (forced - 1)) == 0) groups = forced;
     constexpr int TPB = 256 / TEAM;
     const int64_t blocks = ((int64_t)b.tile_start[b.n] + TPB - 1) / TPB;
-    return launch_claimed(k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>, (int)(blocks < resident ? blocks : resident), TPB, b, s);
+    return launch_claimed(k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>, (int)(blocks < resident ? blocks : resident), TPB, b, s,
+                          1, groups);
 }
 
 template <typename Policy, int DT, bool PACKED>
