@@ -307,3 +307,40 @@ def test_statistics_cache_is_reused(tmp_path):
                               dataset=nncf_amd.Dataset(OnlyFirst()), advanced_parameters=adv)
     for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2), k1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tiny_lm_16bit_models(dtype):
+    """Models usually live in bf16 / fp16: data-free codes must equal the oracle's lowering of the same 16-bit
+    weights (upcast first, weight_lowering.py:493-494), and the data-aware pipeline must run end to end."""
+    import nncf_amd
+    from oracle import wc_oracle as O
+
+    samples = tiny_lm_dataset()
+    ref = make_tiny_lm().to(dtype)
+    model = make_tiny_lm().to(dtype).cuda()
+    nncf_amd.compress_weights(model, mode="int4_sym", group_size=32, dataset=nncf_amd.Dataset(samples[:1]))
+    per = _harvest(model)
+    assert len(per) == 22
+    for name, d in per.items():
+        w = dict(ref.named_modules())[name].weight.detach().float().numpy()
+        four = name not in ("embed", "lm_head")
+        codes, scale, zp = O.compress_weight(w, (1,), "int4_sym" if four else "int8_asym", 32 if four else -1)
+        want = O.pack_int4(codes) if four else codes
+        assert np.array_equal(d["w"].reshape(-1), np.asarray(want).reshape(-1)), name
+        assert np.array_equal(d["s"].reshape(-1), scale.astype(np.float16).reshape(-1)), name
+    assert model.blocks[0].attn.q_proj.weight.dtype == dtype  # decompressed in the layer's dtype
+
+    model = make_tiny_lm().to(dtype).cuda()
+    base = make_tiny_lm().to(dtype).cuda()
+    nncf_amd.compress_weights(model, mode="int4_asym", group_size=32, ratio=0.8, awq=True, scale_estimation=True,
+                              dataset=nncf_amd.Dataset(samples))
+    with torch.no_grad():
+        y, y0 = model(samples[0].cuda()).float(), base(samples[0].cuda()).float()
+    assert torch.isfinite(y).all()
+    assert float((y - y0).abs().max()) < 0.35 * float(y0.abs().max())
+    model = make_tiny_lm().to(dtype).cuda()
+    nncf_amd.compress_weights(model, mode="nf4", group_size=32, gptq=True, dataset=nncf_amd.Dataset(samples))
+    with torch.no_grad():
+        y = model(samples[0].cuda()).float()
+    assert torch.isfinite(y).all() and float((y - y0).abs().max()) < 0.35 * float(y0.abs().max())
