@@ -344,3 +344,68 @@ def test_tiny_lm_16bit_models(dtype):
     with torch.no_grad():
         y = model(samples[0].cuda()).float()
     assert torch.isfinite(y).all() and float((y - y0).abs().max()) < 0.35 * float(y0.abs().max())
+
+
+def _tiny_llama(seed=0):
+    transformers = pytest.importorskip("transformers")
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4,
+                                   num_key_value_heads=2, vocab_size=1000, max_position_embeddings=128,
+                                   tie_word_embeddings=False)
+    torch.manual_seed(seed)
+    return transformers.LlamaForCausalLM(cfg).eval()
+
+
+def _llama_dataset(n=5):
+    g = torch.Generator().manual_seed(5)
+    return [{"input_ids": torch.randint(0, 1000, (1, 24 + i), generator=g),
+             "attention_mask": torch.ones(1, 24 + i, dtype=torch.long)} for i in range(n)]
+
+
+@pytest.mark.parametrize("algo", ["data_free", "awq_se", "gptq", "mixed"])
+def test_hf_llama_architecture(algo):
+    """The driver on a real transformers architecture (LlamaForCausalLM, random init, 3 layers): keyword inputs,
+    rotary embeddings, grouped-query attention, decoder layers called with keyword arguments -- tracing, the AWQ
+    pattern of the gated MLP, the short-circuited layer-wise GPTQ feeder and the parametrized forward all have to
+    work on it."""
+    import nncf_amd
+    from nncf_amd.parameters import AdvancedCompressionParameters, AdvancedGPTQParameters
+
+    data = _llama_dataset()
+    base = _tiny_llama().cuda()
+    model = _tiny_llama().cuda()
+    ids = {k: v.cuda() for k, v in data[0].items()}
+    with torch.no_grad():
+        y0 = base(**ids).logits.float()
+    if algo == "data_free":
+        nncf_amd.compress_weights(model, mode="int4_sym", group_size=64, dataset=nncf_amd.Dataset(data[:1]))
+    elif algo == "awq_se":
+        up_before = model.model.layers[0].mlp.up_proj.weight.detach().clone()
+        nncf_amd.compress_weights(model, mode="int4_asym", group_size=64, awq=True, scale_estimation=True,
+                                  dataset=nncf_amd.Dataset(data))
+    elif algo == "gptq":
+        adv = AdvancedCompressionParameters(gptq_params=AdvancedGPTQParameters(subset_size=5))
+        nncf_amd.compress_weights(model, mode="int4_sym", group_size=64, gptq=True, dataset=nncf_amd.Dataset(data),
+                                  advanced_parameters=adv)
+    else:
+        nncf_amd.compress_weights(model, mode="nf4", group_size=64, ratio=0.7, all_layers=True,
+                                  sensitivity_metric="max_activation_variance", dataset=nncf_amd.Dataset(data))
+    report = model._nncf_amd_weight_compression
+    assert len(report) == 3 * 7 + 2
+    if algo != "mixed":
+        assert report["lm_head"].num_bits == 8 and report["model.embed_tokens"].num_bits == 8
+        assert all(cfg.num_bits == 4 for name, cfg in report.items() if ".layers." in name)
+    else:
+        bits = [cfg.num_bits for cfg in report.values()]
+        assert 4 in bits and 8 in bits
+    with torch.no_grad():
+        y = model(**ids).logits.float()
+    assert torch.isfinite(y).all()
+    assert float((y - y0).abs().max()) < 0.5 * float(y0.abs().max())
+    assert not any("forward" in blk.__dict__ for blk in model.model.layers)  # feeder patches are gone
+    if algo == "awq_se":
+        # MatMul -> Multiply -> MatMul: the activation scale of down_proj was merged into the rows of up_proj
+        from nncf_amd.quantize_model import trace_model
+
+        tr = trace_model(_tiny_llama(), data[0], with_provenance=True)
+        assert tr.producer["model.layers.0.mlp.down_proj"] == ("mul_linear", "model.layers.0.mlp.up_proj")
+        assert not hasattr(model.model.layers[0].mlp.down_proj, "awq_input_scale")
