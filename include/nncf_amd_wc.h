@@ -232,6 +232,19 @@ int nncf_amd_gptq_block(const float* weight, float* quantized, float* err_block,
                         int32_t* zps, int use_given_params, void* stream);
 
 /*
+ * Inverse Cholesky factor of one small SPD block: linv = L^-1 (lower triangle written, the rest left untouched)
+ * with a = L L^T; only the lower triangle of `a` is read.  Base case of the blocked factorization behind GPTQ's
+ * `hessian_inv` (gptq.py:283-285: linalg.cholesky -> cholesky_inverse -> cholesky(upper=True), i.e. the
+ * torch_linalg.py:29-36 calls), one workgroup, n <= 128.
+ *   a: fp32, row pitch lda (elements);  linv: fp32, row pitch ldo;  info: int32 on the device; when the block
+ *   is not positive definite and *info is still 0 it becomes 1 + the index of the first non-positive pivot
+ *   (LAPACK's potrf convention; the caller zeroes it beforehand and reads it once per factorization, so the first
+ *   failing block of a blocked factorization is the one reported).
+ */
+int nncf_amd_cholinv_block(const float* a, int64_t lda, float* linv, int64_t ldo, int64_t n, int32_t* info,
+                           void* stream);
+
+/*
  * Decompressor forward: packed codes -> weights in the layer's dtype in one pass.
  * Replaces INT8/INT4{Asymmetric,Symmetric}WeightsDecompressor.forward (src/nncf/torch/quantization/layers.py:1303-1460)
  * = unpack_uint4/unpack_int4 + decompress_asymmetric/decompress_symmetric

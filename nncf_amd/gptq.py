@@ -178,7 +178,7 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
 
 
 SUPER_BLOCKS = 8  # 128-column blocks per far trailing update (see quantize_weights)
-CHOLINV_BASE = 1024  # below this size the LAPACK-style routines (rocSOLVER potrf, rocBLAS trsm) are used directly
+CHOLINV_BASE = 128  # blocks up to this size go to nncf_amd_cholinv_block (one workgroup)
 
 
 TRI_SPLIT_MIN = 1024  # triangular-aware products split down to this size (measured: 306 -> 231 ms at K = 28672)
@@ -245,7 +245,17 @@ def _syrk_lower_sub(C: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
     return S
 
 
-def _cholinv_lower(A: torch.Tensor, Linv: torch.Tensor) -> None:
+def _cholinv_base(A: torch.Tensor, Linv: torch.Tensor, info: torch.Tensor) -> None:
+    """L^-1 of one block of at most CHOLINV_BASE rows: one workgroup, block in registers (csrc/wc_cholinv.hip),
+    ~0.2 us per column instead of the ~2 us of the library potrf plus a triangular solve against the identity.
+    `info` (int32 on the device) is raised when a pivot is not positive."""
+    if A.dtype != torch.float32 or A.stride(1) != 1 or Linv.stride(1) != 1:
+        raise ValueError("cholinv block: fp32 blocks with unit column stride expected")
+    _lib.check(_lib.lib().nncf_amd_cholinv_block(_lib.ptr(A), A.stride(0), _lib.ptr(Linv), Linv.stride(0),
+                                                 A.shape[0], _lib.ptr(info), _lib.stream_of(A)))
+
+
+def _cholinv_lower(A: torch.Tensor, Linv: torch.Tensor, info: torch.Tensor) -> None:
     """Writes L^-1 (lower triangle; the caller zero-fills the rest) of the SPD matrix A = L L^T into `Linv`; only
     the lower triangle of A is read.  With A = [[A11, .], [A21, A22]]:
         I11 = rec(A11);  L21 = A21 I11^T;  S = A22 - L21 L21^T;  I22 = rec(S);  I21 = -I22 (L21 I11)
@@ -255,18 +265,16 @@ def _cholinv_lower(A: torch.Tensor, Linv: torch.Tensor) -> None:
     complement skip their zero / redundant blocks."""
     n = A.shape[0]
     if n <= CHOLINV_BASE:
-        L = torch.linalg.cholesky(A)
-        eye = torch.eye(n, dtype=A.dtype, device=A.device)
-        Linv.copy_(torch.linalg.solve_triangular(L, eye, upper=False))
+        _cholinv_base(A, Linv, info)
         return
     h = ((n // 2 + 127) // 128) * 128
     if h >= n:
         h = n // 2
     I11 = Linv[:h, :h]
-    _cholinv_lower(A[:h, :h], I11)
+    _cholinv_lower(A[:h, :h], I11, info)
     L21 = _mm_dense_lowerT(A[h:, :h], I11)
     S = _syrk_lower_sub(A[h:, h:], L21)
-    _cholinv_lower(S, Linv[h:, h:])
+    _cholinv_lower(S, Linv[h:, h:], info)
     del S
     tmp = _mm_dense_lower(L21, I11)
     del L21
@@ -283,8 +291,13 @@ def _upper_cholesky_of_inverse(hessian: torch.Tensor) -> torch.Tensor:
     from the GEMM-based recursion `_cholinv_lower`."""
     A = torch.flip(hessian, (0, 1)).contiguous()
     Linv = torch.zeros_like(A)
-    _cholinv_lower(A, Linv)
-    return torch.flip(Linv, (0, 1)).contiguous()
+    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    _cholinv_lower(A, Linv, info)
+    U = torch.flip(Linv, (0, 1)).contiguous()
+    if int(info.item()) != 0:  # one synchronisation per factorization; same failure the reference's cholesky raises
+        msg = "linalg.cholesky: The factorization could not be completed because the input is not positive-definite"
+        raise torch.linalg.LinAlgError(msg)
+    return U
 
 
 def prepare_hinv(hessian: torch.Tensor, damp_percent: float = 0.1):

@@ -47,6 +47,7 @@ def test_argument_validation_without_gpu():
     assert L.nncf_amd_pack_u4(None, 0, None, None) == 0
     assert L.nncf_amd_gptq_block(None, None, None, None, 1, 1, 0, 1, 1, 3, None, None, 0, None) == _lib.ERR_BAD_ARG
     assert L.nncf_amd_hessian_accumulate(None, None, 0, 1, 1, 1.0, 1.0, None) == _lib.ERR_BAD_ARG
+    assert L.nncf_amd_cholinv_block(None, 1, None, 1, 1, None, None) == _lib.ERR_BAD_ARG
     assert L.nncf_amd_reduce_workspace(1, 2048, 4096) > 0
     assert L.nncf_amd_reduce_activation_stats(None, 0, 1, 1, 1, None, None, None, 0, None) == _lib.ERR_BAD_ARG
 

@@ -1,18 +1,25 @@
 """Host-side dense algebra of the GPTQ path that is plain torch (runs on CPU tensors too): the GEMM-based recursive
 Cholesky-with-inverse must equal the reference's chain cholesky -> cholesky_inverse -> cholesky(upper)
-(src/nncf/quantization/algorithms/weight_compression/gptq.py:293-295)."""
+(src/nncf/quantization/algorithms/weight_compression/gptq.py:293-295).  The base case of the recursion is a HIP
+kernel in the product (no CPU path); here it is replaced by a torch stand-in so that the recursion's host logic
+(splits, triangular-aware products, Schur complements, flips) is what gets tested.  The kernel itself is checked on
+the GPU in tests/test_gpu_data_aware.py."""
 import pytest
 import torch
 
 from nncf_amd import gptq as G
 
 
-@pytest.fixture
-def small_bases():
-    old = (G.CHOLINV_BASE, G.TRI_SPLIT_MIN)
-    G.CHOLINV_BASE, G.TRI_SPLIT_MIN = 128, 256
+def _torch_base(A, Linv, info):
+    L = torch.linalg.cholesky(torch.tril(A) + torch.tril(A, -1).T)
+    Linv.copy_(torch.linalg.solve_triangular(L, torch.eye(A.shape[0], dtype=A.dtype), upper=False))
+
+
+@pytest.fixture(autouse=True)
+def small_bases(monkeypatch):
+    monkeypatch.setattr(G, "_cholinv_base", _torch_base)
+    monkeypatch.setattr(G, "TRI_SPLIT_MIN", 256)
     yield
-    G.CHOLINV_BASE, G.TRI_SPLIT_MIN = old
 
 
 @pytest.mark.parametrize("K", [64, 129, 700, 1536])

@@ -192,7 +192,53 @@ def test_se_estimate_matches_the_unfused_chain(mode, gs):
     np.testing.assert_allclose(host(out), host(ref), rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("K", [512, 1152, 2304])
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 63, 64, 65, 100, 127, 128])
+def test_cholinv_block_kernel(n):
+    """nncf_amd_cholinv_block (one workgroup, n <= 128) vs fp64 cholesky + triangular inverse: the block is a
+    strided view inside a larger matrix, its strict upper triangle holds NaN (must not be read), the strict upper
+    triangle and everything outside the block of the output must stay untouched."""
+    from nncf_amd import _lib
+
+    torch.manual_seed(n)
+    x = torch.randn(3 * n + 8, n, device="cuda", dtype=torch.float64)
+    A64 = x.T @ x / n + 0.05 * torch.eye(n, device="cuda", dtype=torch.float64)
+    big = torch.full((n + 5, n + 9), float("nan"), device="cuda")
+    blk = big[3:3 + n, 2:2 + n]
+    blk.copy_(torch.tril(A64.float()) + torch.triu(torch.full((n, n), float("nan"), device="cuda"), 1))
+    out = torch.full((n + 2, n + 3), 7.0, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().nncf_amd_cholinv_block(_lib.ptr(blk), big.stride(0), _lib.ptr(out[1:, 2:]), out.stride(0), n,
+                                                 _lib.ptr(info), _lib.stream_of(big)))
+    assert int(info.item()) == 0
+    A_seen = torch.tril(A64.float()).double()
+    A_seen = A_seen + torch.tril(A_seen, -1).T
+    ref = torch.linalg.inv(torch.linalg.cholesky(A_seen))
+    got = out[1:1 + n, 2:2 + n]
+    upper = torch.triu(torch.ones(n, n, dtype=torch.bool, device="cuda"), 1)
+    assert torch.all(got[upper] == 7.0) and torch.all(out[0] == 7.0) and torch.all(out[:, :2] == 7.0)
+    err = (torch.tril(got).double() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2e-5, float(err)
+
+
+def test_cholinv_block_reports_non_positive_definite():
+    from nncf_amd import _lib
+    from nncf_amd import gptq as G
+
+    n = 40
+    A = torch.eye(n, device="cuda")
+    A[17, 17] = -1.0
+    out = torch.zeros(n, n, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().nncf_amd_cholinv_block(_lib.ptr(A), n, _lib.ptr(out), n, n, _lib.ptr(info), _lib.stream_of(A)))
+    assert int(info.item()) == 18  # LAPACK convention: 1 + index of the failing pivot
+    assert _lib.lib().nncf_amd_cholinv_block(_lib.ptr(A), n, _lib.ptr(out), n, 129, _lib.ptr(info), None) == _lib.ERR_BAD_ARG
+    H = torch.eye(300, device="cuda")
+    H[5, 5] = -2.0
+    with pytest.raises(torch.linalg.LinAlgError):
+        G._upper_cholesky_of_inverse(H)
+
+
+@pytest.mark.parametrize("K", [1, 7, 64, 100, 128, 129, 200, 512, 1152, 2304])
 def test_hinv_recursion_matches_reference_chain(K):
     """`_upper_cholesky_of_inverse` (GEMM-based recursive Cholesky-with-inverse) vs the reference's three-step chain
     cholesky -> cholesky_inverse -> cholesky(upper) (gptq.py:293-295) in fp64 on the same damped Hessian."""
@@ -202,12 +248,7 @@ def test_hinv_recursion_matches_reference_chain(K):
     x = torch.randn(2 * K, K, device="cuda")
     H = x.T @ x / K
     H += 0.1 * torch.mean(torch.diag(H)) * torch.eye(K, device="cuda")
-    old = G.CHOLINV_BASE
-    G.CHOLINV_BASE = 256  # force two levels of recursion at these sizes
-    try:
-        U = G._upper_cholesky_of_inverse(H.clone())
-    finally:
-        G.CHOLINV_BASE = old
+    U = G._upper_cholesky_of_inverse(H.clone())
     H64 = H.double()
     ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H64)), upper=True)
     assert torch.equal(U, torch.triu(U))
