@@ -8,13 +8,23 @@ MI355X-first shape of it:
   (MFMA SYRK, running average of gptq.py:237-240) and the fused token-mean reducer while the hooked forward runs,
   then the forward is cut short (the rest of the model is not needed);
 * Linears that read one activation (q/k/v, gate/up) form one group: ONE Hessian serves all of them;
-* finished decoder blocks (children of an nn.ModuleList) are short-circuited: their forward returns the cached
+* default (`suspend=True`): every calibration sample's forward runs exactly ONCE.  Each sample's forward lives in
+  its own Python thread and is suspended in the pre-hook of the first Linear of every group; the feeder resumes
+  the samples one after the other (strict hand-over: never two threads at once, so the order of every launch is
+  the sequential one), and once all of them wait in front of a group its Hessian is complete.  The caller
+  quantizes the group (in-place `weight.data` swap), the suspended forwards go on through the quantized Linears to
+  the next group.  No prefix is ever recomputed (the re-run scheme below costs about two extra block forwards per
+  block and a model call per sample and group), no assumption about the model's structure is needed, and what a
+  suspended forward holds is its live activations (tens of MB per sample against 288 GB of HBM).
+* `suspend=False`: the re-run scheme.  Every group is a pass over the samples that is cut short at the group;
+  finished decoder blocks (children of an nn.ModuleList) are short-circuited: their forward returns the cached
   output of the latest finished block, so a pass costs the unfinished part of one block, not the model prefix.
   This assumes the blocks of a ModuleList run as a chain (decoder-only transformers); `short_circuit=False` runs the
   real prefix instead.
 """
 from __future__ import annotations
 
+import threading
 from typing import Dict, Iterator, List, Optional, Tuple
 
 import torch
@@ -22,6 +32,9 @@ import torch.nn as nn
 
 from nncf_amd.gptq import HessianAccumulator
 from nncf_amd.statistics import WCTensorStatistic, activation_stats
+
+
+DEFAULT_SUSPEND = True  # see the module docstring; tests flip it to compare the two schemes
 
 
 class _EarlyExit(Exception):
@@ -38,9 +51,54 @@ def _detach(out):
     return out
 
 
+class _SuspendedForward(threading.Thread):
+    """One calibration sample's forward, run in a thread of its own so that it can wait inside a hook."""
+
+    def __init__(self, feeder: "LayerwiseFeeder", item, device, stream):
+        super().__init__(daemon=True)
+        self.feeder, self.item, self.device, self.stream = feeder, item, device, stream
+        self.go = threading.Semaphore(0)
+        self.at: Optional[int] = None  # index of the group this forward waits in front of
+        self.x: Optional[torch.Tensor] = None  # the activation it arrived with
+        self.seen = set()
+        self.started = False
+        self.finished = False
+        self.cancel = False
+        self.error: Optional[BaseException] = None
+
+    def run(self) -> None:
+        self.go.acquire()
+        try:
+            if not self.cancel:
+                self.feeder._tls.worker = self
+                if self.device.type == "cuda":  # current device and stream are per thread
+                    torch.cuda.set_device(self.device)
+                    with torch.cuda.stream(self.stream), torch.no_grad():
+                        self.feeder._forward_fn(self.feeder._model, self.item)
+                else:
+                    with torch.no_grad():
+                        self.feeder._forward_fn(self.feeder._model, self.item)
+        except _EarlyExit:
+            pass
+        except BaseException as e:  # handed to the feeder's thread
+            self.error = e
+        finally:
+            self.at, self.x, self.finished = None, None, True
+            self.feeder._back.release()
+
+    def wait_at(self, gi: int, x: torch.Tensor) -> None:
+        """Called from the hook, in this thread: hand control back and sleep until resumed."""
+        self.at, self.x = gi, x
+        self.feeder._back.release()
+        self.go.acquire()
+        self.at, self.x = None, None
+        if self.cancel:
+            raise _EarlyExit
+
+
 class LayerwiseFeeder:
     def __init__(self, model: nn.Module, dataset, subset_size: int, trace, target_names: List[str],
-                 short_circuit: bool = True):
+                 short_circuit: bool = True, suspend: Optional[bool] = None):
         from nncf_amd.quantize_model import _forward, _model_device, _to_device
 
         self._model, self._forward_fn = model, _forward
@@ -75,6 +133,10 @@ class LayerwiseFeeder:
         self._patched: List[nn.Module] = []
         self._cache: Optional[List] = None
         self._cur = 0
+        self._suspend = DEFAULT_SUSPEND if suspend is None else suspend
+        self._device = device
+        self._tls = threading.local()
+        self._back = threading.Semaphore(0)
 
     # -------------------------------------------------------------------------------------------------
     def _run(self, hook_module: nn.Module, pre_hook=None, post_hook=None) -> None:
@@ -115,7 +177,71 @@ class LayerwiseFeeder:
         self._patched = []
         self._cache = None
 
+    # ------------------------------------------------------------------------------------------------- suspend
+    def _resume(self, w: _SuspendedForward) -> None:
+        """Runs `w` until it waits in front of the next group or ends; only one thread is ever runnable."""
+        if not w.started:
+            w.started = True
+            w.start()
+        w.go.release()
+        self._back.acquire()
+        if w.error is not None:
+            raise w.error
+
+    def _iter_suspended(self) -> Iterator[Tuple[List[str], torch.Tensor, WCTensorStatistic]]:
+        stream = torch.cuda.current_stream(self._device) if self._device.type == "cuda" else None
+        workers = [_SuspendedForward(self, item, self._device, stream) for item in self._samples]
+        handles = []
+
+        def make_pre(gi):
+            def pre(mod, args, kwargs):
+                w = getattr(self._tls, "worker", None)
+                if w is None or gi in w.seen:  # somebody else's forward / the module runs again in this forward
+                    return
+                w.seen.add(gi)
+                w.wait_at(gi, args[0] if args else next(iter(kwargs.values())))
+            return pre
+
+        try:
+            for gi, group in enumerate(self._groups):
+                handles.append(self._mods[group[0]].register_forward_pre_hook(make_pre(gi), with_kwargs=True))
+            for gi, group in enumerate(self._groups):
+                first = self._mods[group[0]]
+                k = first.in_features
+                acc = HessianAccumulator(k, first.weight.device)
+                stats = WCTensorStatistic()
+                for w in workers:
+                    # a forward that reaches the groups in another order than the trace only skips what it missed
+                    while not w.finished and (w.at is None or w.at < gi):
+                        self._resume(w)
+                    if w.finished or w.at != gi:
+                        continue
+                    x = w.x
+                    if x.dtype == torch.float64:
+                        x = x.float()
+                    bs = x.shape[0] if x.ndim == 3 else 1  # gptq.py:226-235
+                    x2 = x.reshape(-1, k)
+                    acc.add(x2, bs)  # buffered: ~32k tokens per MFMA SYRK launch
+                    mean, _ = activation_stats(x2.reshape(1, -1, k), want_stats=False)
+                    stats.mean_values.append(mean.to(x.dtype))
+                    stats.shape_values.append(tuple(x.shape))
+                yield group, acc.result(), stats
+        finally:
+            for w in workers:  # the rest of the model is not needed (or the consumer stopped early)
+                if w.started and not w.finished:
+                    w.cancel = True
+                    w.go.release()
+                    self._back.acquire()
+            for w in workers:
+                if w.started:
+                    w.join()
+            for h in handles:
+                h.remove()
+
     def __iter__(self) -> Iterator[Tuple[List[str], torch.Tensor, WCTensorStatistic]]:
+        if self._suspend:
+            yield from self._iter_suspended()
+            return
         try:
             for gi, group in enumerate(self._groups):
                 first = self._mods[group[0]]

@@ -292,6 +292,11 @@ class WeightCompression:
                                             and ratio != 1.0)
         self._data_aware_compression = ((awq and advanced_parameters.awq_params.prefer_data_aware_scaling)
                                         or scale_estimation or gptq)
+        # The reference collects the per-Linear token means whenever the compression is data-aware; with GPTQ alone
+        # (scale estimation included: gptq.py:319-327 takes its statistics from the layer-wise inputs) nothing reads
+        # them, so the statistics pass over the calibration set is skipped (one full forward per sample).
+        self._needs_token_means = ((awq and advanced_parameters.awq_params.prefer_data_aware_scaling)
+                                   or (scale_estimation and not gptq))
         self.bitwidth_report: Dict[str, Optional[WeightCompressionConfig]] = {}
 
     # ---- algorithm.py:576-620
@@ -410,7 +415,7 @@ class WeightCompression:
         if not targets:
             return {}, {}
         by_name = {wp.module_name: wp for wp in targets}
-        want_mean = bool(self._data_aware_compression)
+        want_mean = bool(self._needs_token_means)
         want_stat = bool(self._data_aware_mixed_precision)
         if want_stat:
             for wp in targets:
@@ -638,7 +643,7 @@ class WeightCompression:
 
     def _statistics_tag(self) -> str:
         """What a statistics cache file must have been collected for to be reusable."""
-        return (f"subset={self._subset_size};mean={int(bool(self._data_aware_compression))};"
+        return (f"subset={self._subset_size};mean={int(bool(self._needs_token_means))};"
                 f"metric={self._sensitivity_metric.value if self._data_aware_mixed_precision else 'none'}")
 
     # ---- algorithm.py:1090-1232
@@ -647,7 +652,7 @@ class WeightCompression:
         self._trace = trace = trace_model(model, example_input, with_provenance=self._awq)
         all_params, ratio_defining, skipped = self.get_weight_compression_parameters(model, trace)
         statistics, activation_scores = None, {}
-        if dataset is not None and (self._data_aware_mixed_precision or self._data_aware_compression):
+        if dataset is not None and (self._data_aware_mixed_precision or self._needs_token_means):
             stat_params = ratio_defining if self._backup_mode == BackupMode.NONE else all_params
             cache = self._adv.statistics_path
             cached = load_statistics(cache, _model_device(model), self._statistics_tag()) if cache else None

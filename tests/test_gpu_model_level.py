@@ -215,6 +215,9 @@ def test_tiny_lm_gptq(se):
     from nncf_amd import layerwise
     from nncf_amd.parameters import AdvancedCompressionParameters, AdvancedGPTQParameters
 
+    import threading
+
+    n_threads = threading.active_count()
     samples = tiny_lm_dataset()
     adv = AdvancedCompressionParameters(gptq_params=AdvancedGPTQParameters(subset_size=6))
 
@@ -241,7 +244,9 @@ def test_tiny_lm_gptq(se):
     tr = trace_model(model, samples[0].cuda())
     feeder = layerwise.LayerwiseFeeder(model, nncf_amd.Dataset(samples), 6, tr, ["blocks.0.attn.q_proj",
                                                                                "blocks.0.attn.k_proj"])
-    group, H, stats = next(iter(feeder))
+    it = iter(feeder)
+    group, H, stats = next(it)
+    it.close()
     assert group == ["blocks.0.attn.q_proj", "blocks.0.attn.k_proj"]
     with torch.no_grad():
         xs = [model.blocks[0].norm1(model.embed(s.cuda())) for s in samples]
@@ -251,14 +256,74 @@ def test_tiny_lm_gptq(se):
     torch.testing.assert_close(stats.mean_values[0], xs[0].mean(dim=(0, 1)), rtol=1e-5, atol=1e-7)
 
     names = [n for n in tr.order if n != "embed"]
-    fast = list(layerwise.LayerwiseFeeder(model, nncf_amd.Dataset(samples), 6, tr, names, short_circuit=True))
+    mk = lambda **kw: list(layerwise.LayerwiseFeeder(model, nncf_amd.Dataset(samples), 6, tr, names, **kw))
+    susp = mk()  # default: every sample's forward runs once, suspended in front of each group
+    fast = mk(suspend=False, short_circuit=True)
     assert "forward" not in model.blocks[0].__dict__  # patches are removed when the feeder is exhausted
-    plain = list(layerwise.LayerwiseFeeder(model, nncf_amd.Dataset(samples), 6, tr, names, short_circuit=False))
-    assert [g for g, _, _ in fast] == [g for g, _, _ in plain] and len(fast) == 13
-    for (g, h1, s1), (_, h2, s2) in zip(fast, plain):
+    plain = mk(suspend=False, short_circuit=False)
+    assert [g for g, _, _ in fast] == [g for g, _, _ in plain] == [g for g, _, _ in susp] and len(fast) == 13
+    for (g, h1, s1), (_, h2, s2), (_, h3, s3) in zip(fast, plain, susp):
         torch.testing.assert_close(h1, h2, rtol=1e-5, atol=1e-7, msg=str(g))
-        for a, b in zip(s1.mean_values, s2.mean_values):
+        torch.testing.assert_close(h3, h2, rtol=1e-5, atol=1e-7, msg=str(g))  # same launches, same order
+        assert len(s3.mean_values) == len(s2.mean_values) == 6
+        for a, b, c in zip(s1.mean_values, s2.mean_values, s3.mean_values):
             torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-8)
+            torch.testing.assert_close(c, b, rtol=1e-6, atol=1e-8)
+    import threading
+    assert threading.active_count() == n_threads  # every suspended forward has ended
+
+    # whole algorithm: both schemes feed GPTQ the same activations -> the same compressed model
+    old = layerwise.DEFAULT_SUSPEND
+    layerwise.DEFAULT_SUSPEND = False
+    try:
+        m_rerun = run(True)
+    finally:
+        layerwise.DEFAULT_SUSPEND = old
+    sd_a, sd_b = m_gptq.state_dict(), m_rerun.state_dict()
+    assert sd_a.keys() == sd_b.keys()
+    for key in sd_a:  # (the Hessian's token-split atomics may reorder sums: allow isolated last-bit flips)
+        a, b = sd_a[key], sd_b[key]
+        if a.dtype in (torch.uint8, torch.int8):
+            assert float((a != b).float().mean()) < 0.01, key
+        else:
+            torch.testing.assert_close(a.float(), b.float(), rtol=1e-2, atol=1e-3 * float(b.float().abs().max()), msg=key)
+
+
+def test_suspended_feeder_cleans_up_on_errors_and_early_stop():
+    """The suspended forwards are threads: they must all have ended when the consumer stops early, when a sample's
+    forward raises, and a module that runs twice per forward must be seen once."""
+    import threading
+
+    import nncf_amd
+    from nncf_amd import layerwise
+    from nncf_amd.quantize_model import trace_model
+
+    samples = tiny_lm_dataset()
+    model = make_tiny_lm().cuda()
+    tr = trace_model(model, samples[0].cuda())
+    names = [n for n in tr.order if n != "embed"]
+    n0 = threading.active_count()
+    it = iter(layerwise.LayerwiseFeeder(model, nncf_amd.Dataset(samples), 6, tr, names))
+    next(it), next(it)
+    assert threading.active_count() == n0 + 6
+    it.close()
+    assert threading.active_count() == n0
+
+    calls = {"n": 0}
+    target = model.blocks[1].mlp if hasattr(model.blocks[1], "mlp") else model.blocks[1]
+
+    def boom(mod, args):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise RuntimeError("boom")
+
+    h = target.register_forward_pre_hook(boom)
+    try:
+        with pytest.raises(RuntimeError, match="boom"):
+            list(layerwise.LayerwiseFeeder(model, nncf_amd.Dataset(samples), 6, tr, names))
+    finally:
+        h.remove()
+    assert threading.active_count() == n0
 
 
 @pytest.mark.parametrize("name", ["int4_asym_g32_r08_awq_se", "int8_asym_tied", "int4_sym_g32"])

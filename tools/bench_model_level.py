@@ -34,7 +34,12 @@ def main():
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--samples", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=1024)
+    ap.add_argument("--only", default="", help="comma-separated substrings of the run names to keep")
+    ap.add_argument("--rerun-feeder", action="store_true", help="GPTQ with the re-run feeder (layerwise.py) for comparison")
     args = ap.parse_args()
+    if args.rerun_feeder:
+        from nncf_amd import layerwise
+        layerwise.DEFAULT_SUSPEND = False
     g = torch.Generator().manual_seed(1)
     data = [{"input_ids": torch.randint(0, 32000, (1, args.tokens), generator=g).cuda()} for _ in range(args.samples)]
     out = {"model": vars(args)}
@@ -45,7 +50,10 @@ def main():
         "int4_sym_g128_gptq": dict(mode="int4_sym", group_size=128, gptq=True, advanced_parameters=AdvancedCompressionParameters(
             gptq_params=AdvancedGPTQParameters(subset_size=args.samples))),
     }
+    keep = [k for k in args.only.split(",") if k]
     for name, kw in runs.items():
+        if keep and not any(k in name for k in keep):
+            continue
         model = build(args)
         params = sum(p.numel() for p in model.parameters())
         ds = nncf_amd.Dataset(data if len(kw) > 2 else data[:1])
