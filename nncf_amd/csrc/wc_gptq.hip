@@ -5,7 +5,7 @@
 // lane j % 16 (interleaved, so that every lane has columns left to update until the end of the sweep).  Per
 // column: the owner's value is broadcast over the 16 lanes (ds_bpermute), every lane quantizes it (same parameters,
 // no divergence) and updates its own remaining columns with the Hinv row from LDS (the 128x128 Hinv block is staged
-// once per workgroup of 16 rows).  Loads and stores of W, Q and Err are coalesced along the row.  The ~K
+// once per workgroup of 32 rows).  Loads and stores of W, Q and Err are coalesced along the row.  The ~K
 // sequential Python iterations x ~10 kernel launches of the reference become K/128 launches; the trailing update
 // W[:, i2:] -= Err @ Hinv[i1:i2, i2:] (gptq.py:363) stays a plain GEMM at the caller.
 //
@@ -20,18 +20,19 @@ namespace wc {
 
 constexpr int GB = 128;   // max columns per call
 constexpr int GLPR = 16;  // lanes per row
-constexpr int GRPB = 16;  // rows per workgroup (256 threads)
+constexpr int GRPB = 32;  // rows per workgroup
+constexpr int GTHR = GRPB * GLPR;  // 512 threads: two workgroups (64 KiB of LDS each) put 4 waves on every SIMD
 constexpr int GCPL = GB / GLPR;  // columns per lane
 
 template <typename Policy>
-__global__ __launch_bounds__(256) void k_gptq_block(const float* __restrict__ weight, float* __restrict__ quantized,
+__global__ __launch_bounds__(GTHR) void k_gptq_block(const float* __restrict__ weight, float* __restrict__ quantized,
                                                     float* __restrict__ err_block, const float* __restrict__ hinv,
                                                     int64_t rows, int64_t K, int64_t i1, int count, int64_t gs, int mode,
                                                     float* scales, int32_t* zps, int given) {
     extern __shared__ float hb[];  // [GB][GB]: Hinv[i1 + i][i1 + j], zero outside the block
     __shared__ float lds[kPolicyLds];
     Policy::init_shared(lds);
-    for (int idx = threadIdx.x; idx < GB * GB; idx += 256) {
+    for (int idx = threadIdx.x; idx < GB * GB; idx += GTHR) {
         const int i = idx / GB, j = idx % GB;
         hb[idx] = (i < count && j < count) ? hinv[(i1 + i) * K + i1 + j] : 0.0f;
     }
@@ -147,13 +148,13 @@ extern "C" int nncf_amd_gptq_block(const float* weight, float* quantized, float*
         attr_set = true;
     }
     if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
-        hipLaunchKernelGGL((k_gptq_block<IntPolicy>), grid, dim3(256), hb_bytes, s, weight, quantized, err_block, hinv, rows, k, i1,
+        hipLaunchKernelGGL((k_gptq_block<IntPolicy>), grid, dim3(GTHR), hb_bytes, s, weight, quantized, err_block, hinv, rows, k, i1,
                            (int)count, gs, mode, scales, zps, use_given_params);
     } else if (mode == NNCF_AMD_NF4) {
-        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<true>>), grid, dim3(256), hb_bytes, s, weight, quantized, err_block, hinv, rows,
+        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<true>>), grid, dim3(GTHR), hb_bytes, s, weight, quantized, err_block, hinv, rows,
                            k, i1, (int)count, gs, mode, scales, zps, use_given_params);
     } else if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) {
-        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<false>>), grid, dim3(256), hb_bytes, s, weight, quantized, err_block, hinv, rows,
+        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<false>>), grid, dim3(GTHR), hb_bytes, s, weight, quantized, err_block, hinv, rows,
                            k, i1, (int)count, gs, mode, scales, zps, use_given_params);
     } else {
         set_error("gptq_block: unsupported mode %d", mode);

@@ -106,3 +106,34 @@ def compress_sharded(weights: Sequence[torch.Tensor], config, compress_fn, gathe
             zp = next(it) if zp_flag else None
             out[i] = (tensor, scale, zp)
     return out
+
+
+def shard_samples(n_samples: int, group=None) -> List[int]:
+    """Calibration samples of this rank when statistics collection is data-parallel: sample i goes to rank
+    i mod world (round-robin keeps the token counts balanced when the set is sorted by length)."""
+    return list(range(dist.get_rank(group), n_samples, dist.get_world_size(group)))
+
+
+def all_gather_sample_statistics(local: Sequence[torch.Tensor], n_samples: int, group=None) -> List[torch.Tensor]:
+    """Data-parallel statistics collection for AWQ / scale estimation: every rank reduced the samples
+    `shard_samples(n_samples)` of ONE activation to a [K] token mean each (collectors.py:512-516 keeps them as a
+    list, one entry per sample); returns the full list in the original sample order on every rank, which is what
+    `process_stats` (activation_stats.py:20-57) expects.  One all_gather_into_tensor of a padded [per_rank, K]
+    block in the statistics' own dtype: bit-identical to a single-rank collection, nothing is summed."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = shard_samples(n_samples, group)
+    assert len(local) == len(mine), (len(local), len(mine))
+    per_rank = -(-n_samples // world)
+    # K and dtype are the same everywhere; a rank without samples learns them from the gathered metadata
+    meta: List = [None] * world
+    dist.all_gather_object(meta, (tuple(local[0].shape), local[0].dtype, str(local[0].device)) if local else None,
+                           group=group)
+    shape, dtype, _ = next(m for m in meta if m is not None)
+    dev = local[0].device if local else torch.device("cuda", torch.cuda.current_device()) \
+        if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    send = torch.zeros((per_rank,) + shape, dtype=dtype, device=dev)
+    if local:
+        send[:len(local)] = torch.stack(list(local))
+    recv = torch.empty((world * per_rank,) + shape, dtype=dtype, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return [recv[(i % world) * per_rank + i // world] for i in range(n_samples)]

@@ -62,6 +62,16 @@ def _worker(rank, world, port, q):
                 and np.array_equal(zp.numpy(), z)
         local_only = compress_sharded(weights, "int4_asym", fake_compress, gather=False)
         ok = ok and 0 < len(local_only) < len(shapes)
+        # data-parallel statistics: 5 samples over 2 ranks (ragged), bf16 means keep their bits and their order
+        from nncf_amd.distributed import all_gather_sample_statistics, shard_samples
+
+        means = [torch.from_numpy(rng.standard_normal(48).astype(np.float32)).to(torch.bfloat16) for _ in range(5)]
+        mine = shard_samples(5)
+        ok = ok and mine == list(range(rank, 5, world))
+        full = all_gather_sample_statistics([means[i] for i in mine], 5)
+        ok = ok and len(full) == 5 and all(torch.equal(a, b) for a, b in zip(full, means))
+        one = all_gather_sample_statistics([means[0]] if rank == 0 else [], 1)  # a rank without samples
+        ok = ok and len(one) == 1 and torch.equal(one[0], means[0])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
