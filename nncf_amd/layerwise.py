@@ -71,9 +71,11 @@ class _SuspendedForward(threading.Thread):
         try:
             if not self.cancel:
                 self.feeder._tls.worker = self
-                if self.device.type == "cuda":  # current device and stream are per thread
+                if self.device.type == "cuda":  # current device, stream and autocast state are per thread
                     torch.cuda.set_device(self.device)
-                    with torch.cuda.stream(self.stream), torch.no_grad():
+                    enabled, dtype = self.feeder._autocast
+                    with torch.cuda.stream(self.stream), torch.no_grad(), \
+                            torch.autocast("cuda", dtype=dtype, enabled=enabled):
                         self.feeder._forward_fn(self.feeder._model, self.item)
                 else:
                     with torch.no_grad():
@@ -190,6 +192,7 @@ class LayerwiseFeeder:
 
     def _iter_suspended(self) -> Iterator[Tuple[List[str], torch.Tensor, WCTensorStatistic]]:
         stream = torch.cuda.current_stream(self._device) if self._device.type == "cuda" else None
+        self._autocast = (torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))
         workers = [_SuspendedForward(self, item, self._device, stream) for item in self._samples]
         handles = []
 

@@ -593,7 +593,15 @@ class WeightCompression:
         feeder = LayerwiseFeeder(model, dataset, p.subset_size, trace, [wp.module_name for wp in targets])
         by_name = {wp.module_name: wp for wp in targets}
         res: Dict[str, CompressedWeight] = {}
-        for group, hessian, stats in feeder:
+        feed = iter(feeder)
+        try:
+            self._gptq_groups(feed, by_name, p, res)
+        finally:
+            feed.close()  # ends the suspended calibration forwards now, also when a group failed
+        return res
+
+    def _gptq_groups(self, feed, by_name, p, res) -> None:
+        for group, hessian, stats in feed:
             # every Linear of `group` reads the same activation: ONE Hessian, ONE Cholesky chain (and one set of token
             # means) serve all of them
             members = [by_name[name] for name in group if by_name[name].compression_config.mode not in INT8_MODES]
@@ -611,7 +619,6 @@ class WeightCompression:
                                                          input_stats=stats, hinv=hinv, dead=dead)
                 wp.module.weight.data = q.to(weight.dtype)
                 res[wp.weight_name] = CompressedWeight(None, scale, zp, None)
-        return res
 
     # ---- torch_backend.py:352-485
     def transform_model(self, all_params, precomputed: Optional[Dict[str, CompressedWeight]]) -> None:
