@@ -256,6 +256,23 @@ def test_hinv_recursion_matches_reference_chain(K):
     assert float(err) < 1e-5, float(err)
 
 
+def test_hinv_full_size_property():
+    """At a BASELINE-sized K (Llama-3-8B hidden = 4096) the fp64 chain is too slow for a test; the size-independent
+    property is used instead: U is upper triangular with a positive diagonal and U^T U H = I."""
+    from nncf_amd import gptq as G
+
+    K = 4096
+    torch.manual_seed(3)
+    x = torch.randn(2 * K, K, device="cuda")
+    x[:, ::97] *= 8.0  # outlier channels, as in calibration activations
+    H = x.T @ x * (2.0 / (2 * K))
+    Hd = H.clone()
+    U, dead = G.prepare_hinv(Hd, 0.1)
+    assert not bool(dead.any()) and torch.equal(U, torch.triu(U)) and bool((torch.diag(U) > 0).all())
+    R = (U.double().T @ U.double()) @ Hd.double() - torch.eye(K, device="cuda", dtype=torch.float64)
+    assert float(R.abs().max()) < 2e-4, float(R.abs().max())
+
+
 def test_hessian_chunking_equals_item_by_item():
     """HessianAccumulator: one SYRK launch per ~32k buffered tokens == the item-by-item running average."""
     from nncf_amd import gptq as G
