@@ -134,12 +134,20 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
     # SUPER-block only (k = 128 GEMM over <= 896 columns); the columns beyond get the errors of all eight blocks in
     # ONE k = 1024 GEMM when the super-block is done.  Same sums, regrouped: the k = 128 update of the whole
     # remainder streams W once per block (4 N K^2 / 128 bytes: 210 GB for 8192 x 28672), this form once per 1024.
+    #
+    # Group parameters are read from W[:, c:c+gs] with every EARLIER block's error applied (gptq.py:312-333, 363).
+    # A group that starts inside a super-block (after its first column) and runs past its end s2 would see columns
+    # [s2, c+gs) without this super-block's pending errors, so the near range of such a super-block is extended to
+    # the end of that group (`near_end`): those columns take the per-block k = 128 updates like the super-block's
+    # own columns, and the far GEMM starts behind them.  Group sizes that divide the super-block (32/64/128/256/...)
+    # or are multiples of it never straddle: near_end == s2.
     super_cols = SUPER_BLOCKS * block_size
     with torch.cuda.device(W.device):
         stream = _lib.stream_of(W)
         for s1 in range(0, K, super_cols):
             s2 = min(s1 + super_cols, K)
-            errs = torch.empty((N, s2 - s1), dtype=torch.float32, device=W.device) if s2 < K else None
+            near_end = near_range_end(s1, s2, gs, K)
+            errs = torch.empty((N, s2 - s1), dtype=torch.float32, device=W.device) if near_end < K else None
             for i1 in range(s1, s2, block_size):
                 i2 = min(i1 + block_size, s2)
                 count = i2 - i1
@@ -162,12 +170,12 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
                 st = L.nncf_amd_gptq_block(_lib.ptr(W), _lib.ptr(Q), _lib.ptr(err), _lib.ptr(hinv), N, K, i1, count, gs,
                                            mode_id, _lib.ptr(scales), _lib.ptr(zps), int(use_se), stream)
                 _lib.check(st)
-                if i2 < s2:
-                    W[:, i2:s2].addmm_(err, hinv[i1:i2, i2:s2], alpha=-1.0)
+                if i2 < near_end:
+                    W[:, i2:near_end].addmm_(err, hinv[i1:i2, i2:near_end], alpha=-1.0)
                 if errs is not None:
                     errs[:, i1 - s1:i2 - s1] = err
             if errs is not None:
-                W[:, s2:].addmm_(errs, hinv[s1:s2, s2:], alpha=-1.0)
+                W[:, near_end:].addmm_(errs, hinv[s1:s2, near_end:], alpha=-1.0)
     out_scales = scales.reshape(N, ngroups, 1)
     out_zps = zps.reshape(N, ngroups, 1) if asym else None
     if config.group_size == -1:
@@ -178,6 +186,19 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
 
 
 SUPER_BLOCKS = 8  # 128-column blocks per far trailing update (see quantize_weights)
+
+
+def near_range_end(s1: int, s2: int, gs: int, K: int) -> int:
+    """End of the column range that must receive every block's error right after the block (not deferred to the
+    super-block's far GEMM) for the super-block [s1, s2): s2 itself, unless a group that starts strictly inside
+    the super-block straddles s2 -- then the end of that group (its parameters are computed from columns up to
+    there while this super-block's errors are still pending, gptq.py:312-333)."""
+    if s2 >= K:
+        return K
+    g0 = (s2 // gs) * gs  # start of the group that holds column s2
+    if s1 < g0 < s2:
+        return min(g0 + gs, K)
+    return s2
 CHOLINV_BASE = 128  # blocks up to this size go to nncf_amd_cholinv_block (one workgroup)
 
 

@@ -605,26 +605,39 @@ def gptq_hessian(inputs, is_3d_weight=False):
     return H
 
 
-def gptq_quantize_weights(hessian, weight, mode, group_size, inputs=None, damp_percent=0.1, block_size=128,
-                          scale_estimation=False, reduction_axes=(1,)):
-    """gptq.py:244-379.  hessian [K,K], weight [N,K] (both are modified like the reference does).
-    Returns (quantized fp32 [N,K], scales, zero_points|None)."""
+def gptq_hinv(hessian, damp_percent=0.1):
+    """gptq.py:269-270, 290-296: dead diagonal, damping, cholesky -> cholesky_inverse -> cholesky(upper).
+    `hessian` [K,K] is modified in place.  Returns (Hinv upper, dead mask)."""
     H = hessian
-    W = weight
     dead = np.diag(H) == 0
     H[dead, dead] = 1
-    W[:, dead] = 0
-    scales, zps = [], []
-    Q = np.zeros_like(W)
     columns = H.shape[0]
-    gs = group_size if group_size != -1 else W.shape[1]
     damp = F32(damp_percent) * np.mean(np.diag(H))
     di = np.arange(columns)
     H[di, di] += damp
     L = np.linalg.cholesky(H)
     Linv = np.linalg.inv(L)                     # numpy_linalg.py:42-48 cholesky_inverse(lower)
     Hi = np.matmul(Linv.T, Linv)
-    Hinv = np.linalg.cholesky(Hi).T.copy()      # upper
+    return np.linalg.cholesky(Hi).T.copy(), dead  # upper
+
+
+def gptq_quantize_weights(hessian, weight, mode, group_size, inputs=None, damp_percent=0.1, block_size=128,
+                          scale_estimation=False, reduction_axes=(1,), hinv=None, dead=None):
+    """gptq.py:244-379.  hessian [K,K], weight [N,K] (both are modified like the reference does).
+    Returns (quantized fp32 [N,K], scales, zero_points|None).
+    `hinv` (+ `dead`): test hook -- the upper factor of gptq.py:296 supplied by the caller (hessian is then unused),
+    so that a comparison can hold the LAPACK step fixed and check the column loop alone."""
+    W = weight
+    if hinv is None:
+        Hinv, dead = gptq_hinv(hessian, damp_percent)
+    else:
+        Hinv = hinv
+        dead = np.zeros(W.shape[1], bool) if dead is None else dead
+    W[:, dead] = 0
+    scales, zps = [], []
+    Q = np.zeros_like(W)
+    columns = Hinv.shape[0]
+    gs = group_size if group_size != -1 else W.shape[1]
     for i1 in range(0, columns, block_size):
         i2 = min(i1 + block_size, columns)
         count = i2 - i1

@@ -160,6 +160,71 @@ def test_gptq_sweep_matches_oracle_given_same_hinv(mode, gs):
     assert np.array_equal(host(Qd)[:, :bs], Q_ref[:, :bs])
 
 
+def _same_hinv_case(N, K, seed):
+    """Weight + the upper factor U of gptq.py:296 computed ONCE in fp64 on the device and rounded to fp32: handed
+    to both the oracle's column loop and gptq.quantize_weights, the LAPACK step drops out of the comparison."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    X = torch.randn(2 * K, K, device="cuda", generator=g, dtype=torch.float64)
+    X[:, ::97] *= 6.0  # outlier channels
+    H = X.T @ X * (2.0 / (2 * K))
+    H += 0.1 * torch.mean(torch.diag(H)) * torch.eye(K, device="cuda", dtype=torch.float64)
+    U = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True).float().contiguous()
+    return W, U
+
+
+# (mode, group size, K, block size): >= 2 super-blocks of 8 blocks with a ragged tail (the far `errs` GEMM of
+# nncf_amd/gptq.py, taken by every BASELINE shape), group sizes that straddle a super-block end (192, 384, 768 with
+# block 128; 128 with block 100), a group size beyond the super-block (1536), per-channel (-1)
+_TWO_LEVEL = [("int4_sym", 64, 1152, 128), ("int4_asym", 128, 1152, 128), ("nf4", 32, 1152, 128),
+              ("int4_sym", 64, 2304, 128), ("int4_asym", 128, 2304, 128), ("nf4", 32, 2304, 128),
+              ("int4_sym", 64, 4096, 128), ("int4_asym", 128, 4096, 128), ("nf4", 32, 4096, 128),
+              ("mxfp4", 32, 2304, 128), ("int8_asym", 128, 1152, 128),
+              ("int4_sym", 192, 2304, 128), ("int4_asym", 384, 2304, 128), ("nf4", 768, 2304, 128),
+              ("int4_sym", 1536, 4608, 128), ("int4_asym", 128, 2304, 100), ("int4_sym", 64, 1600, 50),
+              ("int4_sym", -1, 1152, 128)]
+
+
+@pytest.mark.parametrize("mode,gs,K,bs", _TWO_LEVEL)
+def test_gptq_quantize_weights_two_level_same_hinv(mode, gs, K, bs):
+    """gptq.quantize_weights (two-level trailing update) against the oracle's single-level column loop
+    (gptq.py:298-363) given the SAME fp32 Hinv factor.  Bar: first block bit-exact (no GEMM before it), all blocks
+    >= 99.5 % isclose (the far GEMM sums the same products in another order), scales <= 2e-5, zero points equal on
+    >= 99.5 %."""
+    from nncf_amd import gptq
+    N = 64
+    W, U = _same_hinv_case(N, K, seed=K + bs)
+    q_ref, s_ref, z_ref = O.gptq_quantize_weights(None, host(W).copy(), mode, gs, block_size=bs, hinv=host(U))
+    q, s, z = gptq.quantize_weights(None, W.clone(), _cfg(mode, gs), None, 0.1, bs, False, hinv=U,
+                                    dead=torch.zeros(K, dtype=torch.bool, device="cuda"))
+    assert tuple(s.shape) == s_ref.shape
+    assert np.array_equal(host(q)[:, :bs], q_ref[:, :bs])
+    close = np.isclose(host(q), q_ref, rtol=1e-4, atol=1e-7)
+    assert close.mean() >= 0.995, close.mean()
+    sclose = np.isclose(host(s), s_ref, rtol=2e-5, atol=0)
+    assert sclose.mean() >= 0.995, sclose.mean()
+    if z_ref is None:
+        assert z is None
+    else:
+        assert tuple(z.shape) == z_ref.shape and (host(z) == z_ref).mean() >= 0.995
+
+
+def test_gptq_straddling_group_sees_pending_errors():
+    """Regression for the group-straddles-super-block case: with gs = 192 the group starting at column 960 runs to
+    1152, past the super-block end at 1024; its scale must come from columns that already carry the errors of blocks
+    0..6 (gptq.py:312-333).  The scales of exactly those groups are compared with the oracle at 2e-5."""
+    from nncf_amd import gptq
+    N, K, gs = 32, 2304, 192
+    W, U = _same_hinv_case(N, K, seed=11)
+    _, s_ref, _ = O.gptq_quantize_weights(None, host(W).copy(), "int4_sym", gs, hinv=host(U))
+    _, s, _ = gptq.quantize_weights(None, W.clone(), _cfg("int4_sym", gs), None, hinv=U,
+                                    dead=torch.zeros(K, dtype=torch.bool, device="cuda"))
+    straddlers = [c // gs for c in range(0, K, gs) if (c % 1024) and (c // 1024 != (c + gs - 1) // 1024)]
+    assert straddlers == [5, 10]
+    np.testing.assert_allclose(host(s)[:, straddlers], s_ref[:, straddlers], rtol=2e-5)
+    np.testing.assert_allclose(host(s), s_ref, rtol=2e-5)
+
+
 @pytest.mark.parametrize("mode,gs", [("int4_sym", 32), ("int4_asym", 128), ("int8_asym", 64), ("nf4", 32), ("mxfp4", 32),
                                      ("int4_asym", 30)])
 def test_se_estimate_matches_the_unfused_chain(mode, gs):
