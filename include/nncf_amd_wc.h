@@ -120,6 +120,19 @@ int nncf_amd_int_quant_error(const void* weight, int w_dtype, int64_t outer, int
                              size_t workspace_bytes, void* stream);
 
 /*
+ * The same metric WITHOUT any caller workspace and without any allocation.  No counterpart in the reference: it is
+ * for callers that cannot allocate device memory around the call (HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  The per-channel partial sums live in a 1 MiB device array inside the library (one copy per
+ * GPU, held until the process ends), so outer * inner is limited to NNCF_AMD_STATIC_ERR_MAX_CHANNELS; beyond that the
+ * call returns NNCF_AMD_ERR_WORKSPACE and nncf_amd_int_quant_error with a caller workspace is the way.  Same
+ * kernels, same result bits as nncf_amd_int_quant_error.  All calls on one GPU share that array: calls that overlap
+ * on one GPU (different streams) race; calls on one stream, or on different GPUs, do not.
+ */
+#define NNCF_AMD_STATIC_ERR_MAX_CHANNELS 262144
+int nncf_amd_int_quant_error_static(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
+                                    int64_t group_size, int mode, int reduction, float* result, void* stream);
+
+/*
  * Nibble packing, standalone.  src/nncf/torch/quantization/quantize_functions.py:417-473.
  *   pack_u4: in uint8 [n] (n even) -> out uint8 [n/2];   pack_i4: in int8 (+8 bias first).
  *   unpack_u4 / unpack_i4: the inverses (out has 2*n_packed entries).

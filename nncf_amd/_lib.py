@@ -33,6 +33,8 @@ SIGNATURES = {
     "nncf_amd_int_quant_error_workspace": (c_size_t, [c_int64, c_int64]),
     "nncf_amd_int_quant_error": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nncf_amd_int_quant_error_static": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
+                                                c_void_p, c_void_p]),
     "nncf_amd_pack_u4": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "nncf_amd_pack_i4": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "nncf_amd_unpack_u4": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "wc_common.h"
 
 namespace wc {
@@ -234,6 +236,57 @@ extern "C" int nncf_amd_int_dequantize(const void* codes, int codes_signed, int6
 
 extern "C" size_t nncf_amd_int_quant_error_workspace(int64_t outer, int64_t inner) {
     return (size_t)(outer * inner) * sizeof(float);
+}
+
+// ------------------------------------------------------------------ no-allocation variant of the error metric
+// Per-channel partial sums of nncf_amd_int_quant_error_static live in this file-scope device array instead of a
+// caller workspace.  Every GPU the library runs on holds its own copy (1 MiB) at its own address until the process
+// ends; the host-side name `scratch` is only a handle for hipGetSymbolAddress, never a kernel argument.
+constexpr int64_t kStaticErrChannels = NNCF_AMD_STATIC_ERR_MAX_CHANNELS;
+static __device__ __align__(256) float scratch[kStaticErrChannels];
+constexpr int kScratchDevices = 64;
+static float* g_scratch_ptr[kScratchDevices];  // device address of `scratch` on device i (NULL: not asked yet)
+static std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the CURRENT device, resolved once per device
+static float* scratch_on_current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kScratchDevices) {
+        set_error("int_quant_error_static: no current device or device index %d beyond %d", dev, kScratchDevices - 1);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            set_error("int_quant_error_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    return g_scratch_ptr[dev];
+}
+
+extern "C" int nncf_amd_int_quant_error(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
+                                        int64_t group_size, int mode, int reduction, float* result, void* workspace,
+                                        size_t workspace_bytes, void* stream);
+
+extern "C" int nncf_amd_int_quant_error_static(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
+                                               int64_t group_size, int mode, int reduction, float* result,
+                                               void* stream) {
+    if (outer < 1 || inner < 1 || outer > kStaticErrChannels || inner > kStaticErrChannels ||
+        outer * inner > kStaticErrChannels) {
+        set_error("int_quant_error_static: %lld x %lld channels; this entry point takes 1 .. %lld (use "
+                  "nncf_amd_int_quant_error with a workspace beyond that)", (long long)outer, (long long)inner,
+                  (long long)kStaticErrChannels);
+        return NNCF_AMD_ERR_WORKSPACE;
+    }
+    float* ptr = scratch_on_current_device();
+    if (!ptr) return NNCF_AMD_ERR_LAUNCH;
+    // every channel entry that pass 2 reads is written by pass 1 of the same call: nothing to clear
+    return nncf_amd_int_quant_error(weight, w_dtype, outer, r, inner, group_size, mode, reduction, result, ptr,
+                                    (size_t)kStaticErrChannels * sizeof(float), stream);
 }
 
 extern "C" int nncf_amd_int_quant_error(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,
