@@ -23,6 +23,7 @@ SIGNATURES = {
     "nncf_amd_version": (c_int, []),
     "nncf_amd_last_error": (c_char_p, []),
     "nncf_amd_status_string": (c_char_p, [c_int]),
+    "nncf_amd_reset_claims": (c_int, [c_void_p]),
     "nncf_amd_int_quantize": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nncf_amd_int_quantize_batched": (c_int, [c_int, POINTER(c_void_p), c_int, POINTER(c_int64), POINTER(c_int64),

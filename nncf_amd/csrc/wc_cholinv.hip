@@ -129,12 +129,13 @@ extern "C" int nncf_amd_cholinv_block(const float* a, int64_t lda, float* linv, 
         return NNCF_AMD_ERR_BAD_ARG;
     }
     constexpr size_t lds_bytes = (size_t)(2 * CB * CLD + 2 * CB + 2) * sizeof(float);  // ~130 KiB of dynamic LDS
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr_once;
+    if (attr_once.first_on_device() != 0) {
         if (hipFuncSetAttribute((const void*)k_cholinv_block, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess)
+                                (int)lds_bytes) != hipSuccess) {
+            attr_once.forget_current();
             return launch_status("cholinv_block attribute");
-        attr_set = true;
+        }
     }
     hipLaunchKernelGGL(k_cholinv_block, dim3(1), dim3(256), lds_bytes, (hipStream_t)stream, a, lda, linv, ldo, (int)n,
                        info);

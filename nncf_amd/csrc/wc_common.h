@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/nncf_amd_wc.h"
 
 namespace wc {
@@ -13,6 +15,36 @@ constexpr float kEps = 1.1920928955078125e-07f;  // 2^-23 == fns.finfo(float32).
 
 void set_error(const char* fmt, ...);
 int launch_status(const char* what);
+
+// Per-device "done once" flag for attribute opt-ins (hipFuncSetAttribute is per device): first_on_device() is true
+// the first time it is asked on the current device and false afterwards; thread-safe.
+struct OncePerDevice {
+    std::mutex m;
+    bool seen[64] = {};
+    // returns -1: cannot tell the device, 1: first call on it, 0: seen before
+    int first_on_device() {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+        std::lock_guard<std::mutex> lock(m);
+        if (seen[dev]) return 0;
+        seen[dev] = true;
+        return 1;
+    }
+    void forget_current() {  // the opt-in failed: try again next time
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+        std::lock_guard<std::mutex> lock(m);
+        seen[dev] = false;
+    }
+};
+
+// Work-claim counters of the multi-tensor kernels (wc_group_kernels.h, wc_row_kernels.h); state in wc_misc.hip.
+// kClaimSlots slots per GPU, each kClaimGroups counters kClaimStride words apart (one 128-byte line per counter).
+constexpr int kClaimSlots = 32, kClaimGroups = 128, kClaimStride = 32, kClaimDevices = 64;
+// Counter slot for a launch on stream `s` of the current device: launches on one stream run one after another and
+// share a slot; every other stream seen gets its own (the table holds kClaimSlots streams per device and recycles
+// the least recently used entry beyond that).  *ctr / *done: device addresses of the slot's claim / done counters.
+hipError_t claim_slot(hipStream_t s, uint32_t** ctr, uint32_t** done);
 
 // ---------------------------------------------------------------- 16-byte vectors of the input dtype
 struct alignas(16) Vec16 {

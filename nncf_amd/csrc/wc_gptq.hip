@@ -139,13 +139,14 @@ extern "C" int nncf_amd_gptq_block(const float* weight, float* quantized, float*
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((rows + GRPB - 1) / GRPB));
     constexpr size_t hb_bytes = (size_t)GB * GB * sizeof(float);  // 64 KiB of dynamic LDS
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr_once;
+    if (attr_once.first_on_device() != 0) {
         if (hipFuncSetAttribute((const void*)k_gptq_block<IntPolicy>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_gptq_block<FloatPolicy<true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_gptq_block<FloatPolicy<false>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess)
+            hipFuncSetAttribute((const void*)k_gptq_block<FloatPolicy<false>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess) {
+            attr_once.forget_current();
             return launch_status("gptq_block attribute");
-        attr_set = true;
+        }
     }
     if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
         hipLaunchKernelGGL((k_gptq_block<IntPolicy>), grid, dim3(GTHR), hb_bytes, s, weight, quantized, err_block, hinv, rows, k, i1,

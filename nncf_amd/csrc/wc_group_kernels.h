@@ -226,7 +226,6 @@ constexpr int kClaimGroupsUsed = WC_GROUPS;
 constexpr int kClaimChunk = 3;       // tiles handed out per claim by the multi-tensor tile kernel
 constexpr int kTileClaimGroups = 8;  // parts (sequential streams) of its tile range
 constexpr int kTileBlocksPerCU = 3;  // resident blocks per CU it is launched with
-constexpr int kClaimSlots = 32, kClaimGroups = 128, kClaimStride = 32, kClaimDevices = 16;
 constexpr int kBatchGrid = 2048;  // 256 CUs x 8 blocks; the resident waves stride over the rest
 struct BatchArgs {
     int n;
@@ -238,10 +237,11 @@ struct BatchArgs {
     uint8_t* packed[kMaxBatch];
     float* scale[kMaxBatch];
     void* aux[kMaxBatch];  // int32 zero points (asymmetric integer modes) or uint8 E8M0 scales (MXFP4); may be NULL
-    uint32_t* ctr;                  // claim counters of this launch's slot (kClaimStride words apart)
+    uint32_t* ctr;                  // claim counters of this launch's slot (kClaimStride words apart), zero at launch
+    uint32_t* done;                 // per part: teams that have made their failing claim (same stride), zero at launch
     uint32_t log2_groups;           // claim groups of this launch = 1 << log2_groups (<= grid)
     uint32_t chunk;                 // tiles per claim (k_grouped_batch; 1 for the row kernels' units)
-    uint32_t base[kClaimGroups];    // value of each counter when the launch starts
+    uint32_t teams_on[kClaimGroups];  // teams (waves or blocks) that serve each part
     uint32_t part_lo[kClaimGroups + 1];  // tile range of each part (proportional to the blocks serving it)
 };
 // Tile claim counters.  Waves make unequal progress (the hardware favours the oldest waves: with a static stride
@@ -249,14 +249,12 @@ struct BatchArgs {
 // tiles are claimed: the tile range is cut into 2^k contiguous parts, block x serves part (x / 8) mod 2^k (eight
 // consecutive blocks sit on the eight XCDs: every part is served by all XCDs and by old and young blocks alike),
 // and a wave takes the next tile of its part with one returning atomic add (several counters, because one
-// address sustains only ~10^8 atomics/s).  Counters are never reset: every wave stops at its first failed claim, so a launch adds
-// exactly tiles + waves to a counter and the host keeps the running values (g_claim_host).  Launches take slots
-// round-robin; more than kClaimSlots multi-tensor launches in flight at once (on different streams) would share
-// a slot: not supported.
-static __device__ uint32_t g_claim[kClaimSlots][kClaimGroups][kClaimStride];
-static uint32_t g_claim_host[kClaimDevices][kClaimSlots][kClaimGroups];
-static unsigned g_next_slot[kClaimDevices];
-static std::mutex g_claim_mutex;
+// address sustains only ~10^8 atomics/s).
+// The counters clean up after themselves: every team stops at its first failed claim and then adds one to the part's
+// `done` counter; the team that brings it to the number of teams serving the part knows that nobody will touch the
+// part's counters again and writes both back to zero.  A launch therefore finds zeros and leaves zeros, the host
+// keeps no copy of device state, and a recorded launch (HIP graph) can be replayed.  The state itself (one device
+// array per GPU, slots handed out per stream) lives in wc_misc.hip: claim_slot().
 constexpr int64_t kMaxBatchVec = (int64_t)1 << 30;  // vectors per tensor and per launch (32-bit tile / group indices)
 
 // appends tensor j (nvec 16-byte vectors) to a batch; returns the running tile count
@@ -285,6 +283,15 @@ __device__ __forceinline__ uint32_t claim_async(uint32_t* ctr) {
     const uint32_t zero = 0, one = 1;
     asm volatile("global_atomic_add %0, %1, %2, %3 sc0 sc1" : "=v"(old) : "v"(zero), "v"(one), "s"(ctr) : "memory");  // sc0: return, sc1: agent scope
     return old;
+}
+// Called by ONE lane of a team after its failing claim has RETURNED (so the claim was performed before this add is
+// issued): the last team of the part puts the part's two counters back to zero for the next launch.
+__device__ __forceinline__ void claim_done(uint32_t* ctr, uint32_t* done, uint32_t teams) {
+    const uint32_t d = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d + 1 == teams) {
+        __hip_atomic_exchange(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_exchange(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 __device__ __forceinline__ void dma16_nt(const char* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
@@ -319,7 +326,6 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Vec16* my = stage[wave];
-    const uint32_t total = b.tile_start[b.n];
     const uint32_t lds_base = (uint32_t)(uintptr_t)my;
     uint32_t src_off[VPL];
 #pragma unroll
@@ -368,13 +374,17 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     const uint32_t part = (blockIdx.x >> 3) & ((1u << b.log2_groups) - 1);
     const uint32_t lo = b.part_lo[part], hi = b.part_lo[part + 1];
     uint32_t* ctr = b.ctr + part * kClaimStride;
-    // a claim hands out `chunk` consecutive tiles: claimed value v -> tiles lo + (v - base) * chunk ... (mod 2^32)
-    const uint32_t cbase = b.base[part], chunk = b.chunk;
+    uint32_t* done = b.done + part * kClaimStride;
+    // a claim hands out `chunk` consecutive tiles: claimed value v -> tiles lo + v * chunk ...
+    const uint32_t chunk = b.chunk;
     uint32_t claim = 0;
     if (lane == 0) claim = claim_async(ctr);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
-    uint32_t t = lo + ((uint32_t)__builtin_amdgcn_readfirstlane((int)claim) - cbase) * chunk;
-    if (t >= hi) return;  // (a wave makes exactly one failing claim: the host's running counter values rely on it)
+    uint32_t t = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim) * chunk;
+    if (t >= hi) {  // (a wave makes exactly one failing claim, the last thing it does with the counter)
+        if (lane == 0) claim_done(ctr, done, b.teams_on[part]);
+        return;
+    }
     uint32_t cend = t + chunk < hi ? t + chunk : hi;  // end of the chunk being worked on
 #ifdef WC_CLK  // developer build: per-wave start/end times into scale[0] (read back by tools/kbench.hip, WC_CLK=<file>)
     const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         uint32_t tn = t + 1;
         const bool new_chunk = tn >= cend;  // wave-uniform
-        if (new_chunk) tn = lo + ((uint32_t)__builtin_amdgcn_readfirstlane((int)claim) - cbase) * chunk;
+        if (new_chunk) tn = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim) * chunk;
         Desc nxt = cur;
         if (tn < hi) {
             if (tn >= nxt.end) {
@@ -439,6 +449,7 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
         cur = nxt;
     }
     if (pend_dst) store_packed(pend_dst, pend);
+    if (lane == 0) claim_done(ctr, done, b.teams_on[part]);  // the claim consumed last was the failing one
 #ifdef WC_CLK
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & 63) == 0) {
@@ -463,19 +474,11 @@ static int resident_blocks(Kernel kernel, int max_per_cu = 0) {
     return per_cu * prop.multiProcessorCount;
 }
 
-// Launches a kernel whose teams (`teams_per_block` per block) claim work units: takes a counter slot, fills in
-// the parts and the counters' current values, launches, and advances the host's copy of the counters (every team
-// stops at its first failed claim, so a launch adds units-in-part + teams-on-part to each counter).
+// Launches a kernel whose teams (`teams_per_block` per block) claim work units: takes the stream's counter slot and
+// fills in the parts and the number of teams that serve each (the kernel's clean-up needs it).
 template <typename Kernel>
 static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block, BatchArgs& b, hipStream_t s,
                                  uint32_t chunk = 1, int groups_used = kClaimGroupsUsed) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= kClaimDevices) return hipErrorInvalidDevice;
-    uint32_t* sym = nullptr;
-    e = hipGetSymbolAddress((void**)&sym, HIP_SYMBOL(g_claim));
-    if (e != hipSuccess) return e;
     const uint32_t units = b.tile_start[b.n];
     if (blocks < 1) return hipSuccess;
     int lg = 0;
@@ -483,25 +486,19 @@ static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block,
     const int groups = 1 << lg;
     uint32_t blocks_on[kClaimGroups] = {};
     for (int x = 0; x < blocks; ++x) ++blocks_on[(x >> 3) & (groups - 1)];
-    std::lock_guard<std::mutex> lock(g_claim_mutex);
-    const unsigned slot = g_next_slot[dev]++ % kClaimSlots;
-    uint32_t* shadow = g_claim_host[dev][slot];
-    b.ctr = sym + (size_t)slot * kClaimGroups * kClaimStride;
+    hipError_t e = claim_slot(s, &b.ctr, &b.done);
+    if (e != hipSuccess) return e;
     b.log2_groups = (uint32_t)lg;
     b.chunk = chunk;
     uint32_t seen = 0;
     for (int g = 0; g < groups; ++g) {
-        b.base[g] = shadow[g];
+        b.teams_on[g] = (uint32_t)teams_per_block * blocks_on[g];
         b.part_lo[g] = (uint32_t)((uint64_t)units * seen / (uint32_t)blocks);
         seen += blocks_on[g];
     }
     b.part_lo[groups] = units;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
-    e = hipPeekAtLastError();
-    if (e != hipSuccess) return e;
-    for (int g = 0; g < groups; ++g)
-        shadow[g] += (b.part_lo[g + 1] - b.part_lo[g] + chunk - 1) / chunk + (uint32_t)teams_per_block * blocks_on[g];
-    return hipSuccess;
+    return hipPeekAtLastError();
 }
 
 // grid of a multi-tensor launch: one resident set of blocks (never a second, under-occupied round), at most one

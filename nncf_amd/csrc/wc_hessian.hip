@@ -584,12 +584,13 @@ static int hessian_accumulate_impl(float* h, const void* x, int x_dtype, int64_t
         dim3 g16((unsigned)prs, (unsigned)sp);
         if (big) {
             constexpr size_t lds_bytes = (size_t)GST * 2 * GK * GROW;  // 131072
-            static bool attr_set = false;
-            if (!attr_set) {
+            static OncePerDevice attr_once;
+            if (attr_once.first_on_device() != 0) {
                 if (hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-                    hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                    hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+                    attr_once.forget_current();
                     return launch_status("hessian_syrk16b attribute");
-                attr_set = true;
+                }
             }
             if (x_dtype == NNCF_AMD_BF16)
                 hipLaunchKernelGGL((k_syrk16b<NNCF_AMD_BF16>), g16, dim3(256), lds_bytes, s, h, x, tokens, k, alpha, nt, rps);

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
     (void)lo;
     (void)total;
     uint32_t* ctr = b.ctr + part * kClaimStride;
-    const uint32_t cbase = lo - b.base[part];
+    uint32_t* done = b.done + part * kClaimStride;
+    const uint32_t cbase = lo;
     // team-uniform claim: a wave claims for itself, a block through thread 0 and LDS
     uint32_t claim = 0;
     auto claim_issue = [&]() {
@@ -112,7 +113,10 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
     uint32_t r = claim_take();
     parity ^= 1;  // (block teams) the slot just read must not be rewritten before everybody has read it
-    if (r >= hi) return;
+    if (r >= hi) {  // (a team makes exactly one failing claim, the last thing it does with the counter)
+        if (TEAM == 64 ? lane == 0 : threadIdx.x == 0) claim_done(ctr, done, b.teams_on[part]);
+        return;
+    }
     Row cd = locate(r), nd = cd;
     Vec16 cur[KEEP];
     if constexpr (DMA) issue_dma(cd);
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
             claim_issue();
         }
     }
+    if (TEAM == 64 ? lane == 0 : threadIdx.x == 0) claim_done(ctr, done, b.teams_on[part]);  // rn was the failing claim
 }
 
 // team/keep class of a row of `vpr` 16-byte vectors; 0 = does not fit (longer than 4096 vectors)

@@ -179,3 +179,24 @@ def test_packed_fast_paths_adversarial(mode, dtype):
             assert np.array_equal(np.ldexp(np.float32(1), host(cw.codebook).astype(np.int32) - 127).reshape(rs.shape), rs)
     single = wl.compress_weight_packed(to_dev(w32, dtype), (1,), _cfg(mode, gs))
     assert np.array_equal(host(single.tensor), host(got[0].tensor))
+
+
+@pytest.mark.parametrize("mode", ["nf4", "mxfp4"])
+def test_c5_batched_full_size_vs_oracle(mode):
+    """BASELINE configs[4] shapes (Mixtral expert w1 14336 x 4096 and w2 4096 x 14336, g32) + a ragged tensor whose
+    last tile is partial, through the multi-tensor kernel in one launch, against the oracle on the WHOLE tensors:
+    every 4-bit code decodes to the oracle's value, scales (and E8M0 bytes) bit-exact."""
+    from nncf_amd import weight_lowering as wl
+    torch.manual_seed(9)
+    ws = [(torch.randn(r, c, device="cuda") * 0.02).to(torch.bfloat16) for r, c in [(14336, 4096), (4096, 14336), (333, 4096)]]
+    ws[2][5, 64:96] = 0.0
+    got = wl.compress_weights_packed_batched(ws, _cfg(mode, 32), want_e8m0=True)
+    lut = O.NF4_QUANTILES if mode == "nf4" else O.E2M1_VALUE_OF_CODE
+    for w, cw in zip(ws, got):
+        rc, rs, _ = O.compress_weight(host(w.float()), (1,), mode, 32)
+        assert_equal_nan(host(cw.scale).reshape(rs.shape), rs, "scale")
+        p = host(cw.tensor).ravel()
+        codes = np.stack([p & 15, p >> 4], -1).ravel()
+        assert np.array_equal(lut[codes], rc.ravel())
+        if mode == "mxfp4":
+            assert np.array_equal(np.ldexp(np.float32(1), host(cw.codebook).astype(np.int32).ravel() - 127), rs.ravel())

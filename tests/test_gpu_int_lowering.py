@@ -229,28 +229,102 @@ def test_batched_matches_single_and_oracle(mode, gs, dtype):
                 assert np.array_equal(np.ldexp(np.float32(1), host(cw.codebook).astype(np.int32).ravel() - 127), rs.ravel())
 
 
+def _oracle_packed(w, mode, gs):
+    """(packed codes or int8 codes, scale, zp) of the oracle for a device tensor."""
+    rc, rs, rz = O.compress_weight(host(w.float()), (1,), mode, gs)
+    if mode == "int4_sym":
+        rc = O.pack_int4(rc)
+    elif mode == "int4_asym":
+        rc = O.pack_uint4(rc)
+    return rc, rs, rz
+
+
+def _assert_cw_equals_oracle(cw, ref, what=""):
+    rc, rs, rz = ref
+    assert_equal_nan(host(cw.tensor).reshape(rc.shape), rc, what + " codes")
+    assert_equal_nan(host(cw.scale).reshape(rs.shape), rs, what + " scale")
+    if rz is not None:
+        assert_equal_nan(host(cw.zero_point).reshape(rz.shape), rz, what + " zp")
+
+
 def test_claim_counters_survive_many_launches():
-    """The multi-tensor kernel hands tiles out through counters that are never reset (the host tracks their running
-    values per slot): many launches of changing sizes, cycling every slot several times, must keep giving the same
-    answer -- a drifted counter would skip or repeat tiles."""
+    """The multi-tensor kernels hand tiles out through device counters that every launch must leave at zero (the
+    last team of a part resets them).  Many launches of changing sizes and both kernel families (tile / row) on one
+    stream: every result is compared with the ORACLE's packed codes, scales, zero points -- a counter left non-zero
+    would skip or repeat tiles in the launch after it."""
     from nncf_amd import weight_lowering as wl
     torch.manual_seed(1)
+    sets = [("int4_sym", 128, [(4096, 4096), (1024, 4096), (14336, 4096)]), ("int4_sym", 128, [(8, 128)]),
+            ("int4_asym", 128, [(3, 256), (515, 1024), (64, 2048)]), ("int8_asym", -1, [(2048, 8192)] * 3),
+            ("int4_sym", 128, [(2048, 8192)] * 5), ("int8_sym", -1, [(77, 512), (300, 14336)])]
+    data = [(m, gs, [(torch.randn(r, c, device="cuda") * 0.02).to(torch.bfloat16) for r, c in shapes])
+            for m, gs, shapes in sets]
+    want = [[_oracle_packed(w, m, gs) for w in ws] for m, gs, ws in data]
+    for it in range(90):
+        k = it % len(data)
+        m, gs, ws = data[k]
+        got = wl.compress_weights_packed_batched(ws, _cfg(m, gs))
+        if it < 12 or it % 7 == 0 or it > 80:
+            for ref, cw in zip(want[k], got):
+                _assert_cw_equals_oracle(cw, ref, f"iteration {it} set {k}")
+
+
+def test_claim_slots_streams_graph_replay_and_reset():
+    """(1) launches on several streams at once take different counter slots; (2) a recorded multi-tensor launch can
+    be replayed (the counters return to zero by themselves, the host keeps no copy of them); (3)
+    nncf_amd_reset_claims leaves a working state.  All results against the oracle."""
+    from nncf_amd import _lib, weight_lowering as wl
+    torch.manual_seed(2)
     cfg = _cfg("int4_sym", 128)
-    sets = [[(torch.randn(r, c, device="cuda") * 0.02).to(torch.bfloat16) for r, c in shapes]
-            for shapes in ([(4096, 4096), (1024, 4096), (14336, 4096)], [(8, 128)], [(3, 256), (515, 1024), (64, 2048)],
-                           [(2048, 8192)] * 5)]
-    want = [[(cw.tensor.clone(), cw.scale.clone()) for cw in wl.compress_weights_packed_batched(ws, cfg)] for ws in sets]
-    for it in range(120):
-        k = it % len(sets)
-        got = wl.compress_weights_packed_batched(sets[k], cfg)
-        if it % 7 == 0 or it > 100:
-            for (t, s), cw in zip(want[k], got):
-                assert torch.equal(t, cw.tensor) and torch.equal(s, cw.scale), f"iteration {it}"
-    # a tensor with the sentinel pattern: every packed byte must have been written exactly by its own tile
-    w = sets[0][2]
-    out = wl.compress_weight_packed(w, (1,), cfg)
-    ref = wl.compress_weight(w, (1,), cfg)
-    assert torch.equal(wl.pack_int4(ref.tensor), out.tensor)
+    ws = [(torch.randn(r, c, device="cuda") * 0.02).to(torch.bfloat16) for r, c in [(2048, 4096), (512, 1024), (4096, 4096)]]
+    want = [_oracle_packed(w, "int4_sym", 128) for w in ws]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    results = []
+    for rep in range(3):
+        for st in streams:
+            with torch.cuda.stream(st):
+                results.append(wl.compress_weights_packed_batched(ws, cfg))
+    torch.cuda.synchronize()
+    for got in results:
+        for ref, cw in zip(want, got):
+            _assert_cw_equals_oracle(cw, ref, "streams")
+    # graph: record one batched call, replay it five times into the same output buffers
+    gstream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(gstream):
+        wl.compress_weights_packed_batched(ws, cfg)  # warm-up on the capture stream (slot + symbol look-ups)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=gstream):
+        captured = wl.compress_weights_packed_batched(ws, cfg)
+    for rep in range(5):
+        for cw in captured:
+            cw.tensor.zero_()
+            cw.scale.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for ref, cw in zip(want, captured):
+            _assert_cw_equals_oracle(cw, ref, f"graph replay {rep}")
+    _lib.check(_lib.lib().nncf_amd_reset_claims(_lib.stream_of(ws[0])))
+    for ref, cw in zip(want, wl.compress_weights_packed_batched(ws, cfg)):
+        _assert_cw_equals_oracle(cw, ref, "after reset")
+
+
+@pytest.mark.parametrize("mode,gs", [("int4_sym", 128), ("int4_asym", 128), ("int4_sym", 64), ("int8_asym", -1),
+                                     ("int8_sym", -1), ("int4_sym", -1)])
+def test_batched_kernel_full_size_vs_oracle(mode, gs):
+    """The multi-tensor kernels -- the ones bench.py times -- against the oracle on WHOLE BASELINE-sized tensors
+    (Llama-3-8B gate_proj 14336 x 4096, q_proj 4096 x 4096, down_proj 4096 x 14336 and a ragged 1000 x 4096 whose
+    last tile is partial) in one launch: every code byte, scale and zero point bit-exact."""
+    from nncf_amd import weight_lowering as wl
+    torch.manual_seed(4)
+    ws = [(torch.randn(r, c, device="cuda") * 0.02).to(torch.bfloat16)
+          for r, c in [(14336, 4096), (4096, 4096), (4096, 14336), (1000, 4096)]]
+    ws[1][17, 256:384] = 0.0          # an all-zero group
+    ws[1][18, :] = 0.5                # constant row
+    got = wl.compress_weights_packed_batched(ws, _cfg(mode, gs))
+    for w, cw in zip(ws, got):
+        _assert_cw_equals_oracle(cw, _oracle_packed(w, mode, gs), f"{mode} g{gs} {tuple(w.shape)}")
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
