@@ -227,6 +227,32 @@ int nncf_amd_se_estimate(const float* weight, const float* importance, int64_t n
                          const float* scale, const float* zero_point, float zero_scale, float* out, void* stream);
 
 /*
+ * One whole search step of scale estimation for a weight (scale_estimation.py:268-360), fused: candidate scale ->
+ * quantize -> ideal-scale estimate (`near`) -> quantize-dequantize with `near` -> output error of every group against
+ * the cached fp_outs (the [group_size x n_samples] activation slice sits in LDS, the contraction runs on the fp32 MFMA)
+ * -> the reference's masked blends of best_diffs / result_scale.
+ *   weight, importance: fp32 [batch, rows, groups, group_size] (grouped view of the [rows, groups*group_size] weight);
+ *   x: fp32 [batch, groups, group_size, n_samples] (process_stats' X, grouped, :249);
+ *   fp_outs: fp32 [batch, groups, rows, n_samples] = matmul(moveaxis(weight, -2, -3), x) (:250);
+ *   scale0 (the min-max scale), zero_point (fp32, NULL for symmetric / float modes), best_diffs, result_scale:
+ *   fp32 [batch, rows, groups].
+ *   kind 0: near = scale0, best_diffs = diff, result_scale = scale0 (the min-max baseline, :252-262);
+ *   kind 1: candidate = result_scale (rectification step, :268-298); kind 2: candidate = factor * scale0 (grid step,
+ *   :300-360); both update best_diffs / result_scale in place.  weight_penalty <= 0 disables the penalty term.
+ * group_size in {32, 64, 128}, 1 <= n_samples <= 64 (nncf_amd_se_step_supported); other shapes take the unfused path
+ * of the host mirror.  nncf_amd_se_importance writes the normalised importance (:236-247) from the per-channel
+ * statistic s [batch, groups*group_size].
+ */
+int nncf_amd_se_step_supported(int64_t group_size, int64_t n_samples);
+int nncf_amd_se_step(const float* weight, const float* importance, const float* x, const float* fp_outs,
+                     const float* scale0, const float* zero_point, float* best_diffs, float* result_scale,
+                     int64_t batch, int64_t rows, int64_t groups, int64_t group_size, int64_t n_samples, int mode,
+                     int kind, float factor, float zero_scale, float weight_penalty, void* stream);
+int nncf_amd_se_importance(const float* weight, const float* s_per_channel, const float* scale0,
+                           const float* zero_point, int64_t batch, int64_t rows, int64_t groups, int64_t group_size,
+                           int mode, float* importance, void* stream);
+
+/*
  * Token mean of a LIST of separately allocated activation samples x_i[tokens_i, hidden] (one calibration item each):
  * the per-item MeanReducer of the statistics the data-aware algorithms consume (WCTensorStatistic.mean_values,
  * src/nncf/quantization/algorithms/weight_compression/gptq.py:381-396; MeanReducer collectors.py:512-518), two

@@ -50,6 +50,12 @@ SIGNATURES = {
                                                  c_void_p, c_size_t, c_void_p]),
     "nncf_amd_se_estimate": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p,
                                      c_void_p]),
+    "nncf_amd_se_step_supported": (c_int, [c_int64, c_int64]),
+    "nncf_amd_se_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_float, c_float, c_float,
+                                 c_void_p]),
+    "nncf_amd_se_importance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                       c_int, c_void_p, c_void_p]),
     "nncf_amd_decompress": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "nncf_amd_token_mean_workspace": (c_size_t, [c_int, c_int64, c_int64]),
     "nncf_amd_token_mean_batched": (c_int, [c_int, POINTER(c_void_p), c_int, POINTER(c_int64), c_int64, c_void_p, c_void_p,

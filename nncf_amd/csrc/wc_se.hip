@@ -88,3 +88,467 @@ extern "C" int nncf_amd_se_estimate(const float* weight, const float* importance
     }
     return launch_status("se_estimate");
 }
+
+// ====================================================================================================================
+// Fused search step of scale estimation (scale_estimation.py:268-360), one launch per candidate:
+//     cand  = result_scale (rectification steps) | factor * scale0 (grid steps)
+//     near  = sign(scale0) * sum_k |w_k| / (|q(w_k; cand) - zp| + zero_mask_k) * importance_k        (:380-409)
+//     dq    = quantize-dequantize(w; near, zp)
+//     diff  = mean_j (fp_outs[j] - sum_k dq_k X[k, j])^2  [+ weight_penalty * mean_k (dq_k - w_k)^2]
+//     mask  = diff > best;  best = mask*best + (1-mask)*diff;  result = mask*result + (1-mask)*near
+// instead of the estimate kernel + a QDQ pass that writes the dequantized weight + a batched matmul that reads it back
+// (through a transposing copy) + ~8 elementwise launches.  The weight and the importance are read once per step
+// (8 B per element); the group's slice of the activation subset X[g] (GS x <= 64 samples) sits in LDS; the small
+// contraction runs on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), 16 rows of one group per wave:
+//   A operand  lane (r = lane % 16, q = lane / 16) supplies dq[row r][k = q*GS/4 + p] in MFMA number p, i.e. a lane owns
+//              one quarter of a row's group (GS/4 consecutive elements) -- the k order of the sum is ours to choose;
+//   B operand  lane (c = lane % 16, q) supplies X[g][q*GS/4 + p][t*16 + c] for the sample tiles t = 0..3 with ONE
+//              16-byte LDS read (the four tiles of a (k, c) pair are stored next to each other);
+//   C          4 registers per 16-sample tile: rows 4q + i, column c.
+// Rows arrive coalesced (whole 4*GS-byte row segments per load instruction) and are transposed to the lane-owns-
+// quarter-row layout through a wave-private LDS buffer.  A block serves one group column (X slice staged once) and
+// strides over the row tiles.  (A 32x32x2 tiling with half rows per lane needs 2x the registers: measured slower.)
+namespace wc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SeStepArgs {
+    const float* w;        // [batch, rows, groups, GS]
+    const float* imp;      // same shape (unused by kind 0)
+    const float* x;        // [batch, groups, GS, ns]
+    const float* fp_outs;  // [batch, groups, rows, ns]
+    const float* scale0;   // [batch, rows, groups] min-max scale
+    const float* zp;       // same shape or NULL
+    float* best;           // same shape, in/out (out only for kind 0)
+    float* result;         // same shape, in/out (out only for kind 0)
+    int64_t rows, groups;
+    int ns, mode, kind;
+    float factor, zero_scale, weight_penalty;
+};
+
+template <int M>
+__device__ __forceinline__ typename IntPolicyT<M>::Par se_par(const IntPolicyT<M>& pol, float sc, float zpf, bool has_zp) {
+    typename IntPolicyT<M>::Par p;
+    p.scale = sc;
+    p.has_zp = has_zp;
+    p.zpf = has_zp ? zpf : 0.0f;
+    p.zpi = (int)p.zpf;
+    pol.finish(p);
+    return p;
+}
+template <bool NF4, int M>
+__device__ __forceinline__ typename FloatPolicy<NF4, M>::Par se_par(const FloatPolicy<NF4, M>& pol, float sc, float, bool) {
+    return pol.with_reciprocal(sc);
+}
+// values (the unscaled quantized tensor as float) of N elements sharing one parameter set; in and out may alias
+template <int N, int M>
+__device__ __forceinline__ void se_values(const IntPolicyT<M>& pol, const typename IntPolicyT<M>::Par& p, const float* in,
+                                          float* out) {
+    pol.template quant_n<N>(p, in, out);
+}
+template <int N, bool NF4, int M>
+__device__ __forceinline__ void se_values(const FloatPolicy<NF4, M>& pol, const typename FloatPolicy<NF4, M>::Par& p,
+                                          const float* in, float* out) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        int code;
+        float v;
+        pol.quant(in[i], p, code, v);
+        out[i] = v;
+    }
+}
+
+// 16 rows of one group, coalesced (whole 4*GS-byte row segments per load instruction) -> registers of the lane that
+// owns the quarter row (lane % 16 = row, lane / 16 = quarter), through the wave's staging buffer.
+// The group of row n starts at base + (gbase + n * G) * GS.
+template <int GS>
+__device__ __forceinline__ void se_load_rows(const float* __restrict__ base, float (&out)[GS / 4], float* stage, int64_t n0,
+                                             int64_t N, int64_t gbase, int64_t G, int lane) {
+    constexpr int QUART = GS / 4, SP = GS + 4, LPR = GS / 4, RPI = 64 / LPR, NLD = 16 / RPI;
+    const int r = lane & 15, q = lane >> 4;
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
+    float4 v[NLD];
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) {
+        const int64_t gr = n0 + t * RPI + lr;
+        const int64_t grc = gr < N ? gr : N - 1;
+        v[t] = *(const float4*)(base + (gbase + grc * G) * GS + lc);
+    }
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) *(float4*)(stage + (t * RPI + lr) * SP + lc) = v[t];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float* src = stage + r * SP + q * QUART;
+#pragma unroll
+    for (int i = 0; i < QUART / 4; ++i) {
+        const float4 x = *(const float4*)(src + 4 * i);
+        out[4 * i] = x.x, out[4 * i + 1] = x.y, out[4 * i + 2] = x.z, out[4 * i + 3] = x.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kSeWaves = 12;  // 133 KiB of LDS: one block per CU, three waves per SIMD
+constexpr int kSeThreads = kSeWaves * 64;
+template <int GS>
+constexpr int se_lds_floats() {
+    return GS * 64 + kSeWaves * 16 * (GS + 4) + kSeWaves * 16 + kPolicyLds;
+}
+
+// NT: 16-sample tiles of the MFMA (1, 2 or 4)
+template <typename Policy, int GS, int NT>
+__global__ __launch_bounds__(kSeThreads) void k_se_step(SeStepArgs a) {
+    constexpr int QUART = GS / 4;  // elements a lane owns
+    constexpr int SP = GS + 4;     // pitch (floats) of a staged row: +16 B
+    extern __shared__ __align__(16) float se_smem[];
+    float* Xs = se_smem;  // [GS][16 columns][4 tiles]: sample column j of row k at k*64 + (j%16)*4 + j/16
+    float* lut = Xs + GS * 64 + kSeWaves * 16 * SP + kSeWaves * 16;
+    Policy::init_shared(lut);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* stage = Xs + GS * 64 + wave * 16 * SP;
+    float* dsh = Xs + GS * 64 + kSeWaves * 16 * SP + wave * 16;
+    const int64_t g = blockIdx.y, e = blockIdx.z, N = a.rows, G = a.groups;
+    const int ns = a.ns;
+    {
+        const float* xg = a.x + ((e * G + g) * GS) * ns;
+        if (ns == 64 && (((uintptr_t)xg) & 15u) == 0) {
+            for (int idx = threadIdx.x; idx < GS * 16; idx += kSeThreads) {
+                const float4 v = ((const float4*)xg)[idx];
+                const int row = idx >> 4, j0 = (idx & 15) * 4;  // columns j0 .. j0+3
+                float* dst = Xs + row * 64 + (j0 & 15) * 4 + (j0 >> 4);
+                dst[0] = v.x, dst[4] = v.y, dst[8] = v.z, dst[12] = v.w;
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < GS * 64; idx += kSeThreads) {
+                const int row = idx >> 6, j = idx & 63;
+                Xs[row * 64 + (j & 15) * 4 + (j >> 4)] = j < ns ? xg[row * ns + j] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    GroupArgs ga = {};
+    ga.mode = a.mode;
+    const Policy pol(ga, lut);
+    const int r = lane & 15, q = lane >> 4;
+    const bool has_zp = a.zp != nullptr;
+    const float* fo = a.fp_outs + ((e * G + g) * N) * ns;
+    // a block serves ONE group column g (its X slice stays in LDS) and every gridDim.x-th set of four 16-row tiles
+    for (int64_t n0 = ((int64_t)blockIdx.x * kSeWaves + wave) * 16; n0 < N; n0 += (int64_t)gridDim.x * kSeWaves * 16) {
+        const int64_t row = n0 + r;
+        const int64_t rowc = row < N ? row : N - 1;
+        const int64_t pidx = (e * N + rowc) * G + g;
+        const float sc0 = a.scale0[pidx];
+        const float zpf = has_zp ? a.zp[pidx] : 0.0f;
+        float wv[QUART];
+        se_load_rows<GS>(a.w, wv, stage, n0, N, (e * N) * G + g, G, lane);
+        float near = sc0;
+        constexpr int C = QUART < 8 ? QUART : 8;
+        if (a.kind != 0) {
+            float iv[QUART];
+            se_load_rows<GS>(a.imp, iv, stage, n0, N, (e * N) * G + g, G, lane);
+            const float cand = a.kind == 1 ? a.result[pidx] : a.factor * sc0;
+            const typename Policy::Par pc = se_par(pol, cand, zpf, has_zp);
+            float acc = 0.0f;
+#pragma unroll
+            for (int c0 = 0; c0 < QUART; c0 += C) {
+                float val[C];
+                se_values<C>(pol, pc, wv + c0, val);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const float target = pol.target(val[i], pc);
+                    const float zm = fabsf(target) <= 1e-8f ? a.zero_scale : 0.0f;  // isclose(target, 0): atol 1e-8
+                    acc += fabsf(wv[c0 + i]) / (fabsf(target) + zm) * iv[c0 + i];
+                }
+            }
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            near = acc * (sc0 / fabsf(sc0));  // scale_sign = scale / |scale|  (scale_estimation.py:264)
+        }
+        // quantize-dequantize with `near`, in place; optional weight penalty
+        const typename Policy::Par pn = se_par(pol, near, zpf, has_zp);
+        float pen = 0.0f;
+        const bool want_pen = a.weight_penalty > 0.0f;  // uniform
+#pragma unroll
+        for (int c0 = 0; c0 < QUART; c0 += C) {
+            float val[C];
+            se_values<C>(pol, pn, wv + c0, val);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const float dq = pol.dq(0, val[i], pn);
+                if (want_pen) {
+                    const float d = dq - wv[c0 + i];
+                    pen += d * d;
+                }
+                wv[c0 + i] = dq;
+            }
+        }
+        // q_outs[row][j] = sum_k dq[row][k] X[k][j] on the fp32 MFMA: MFMA number p multiplies the k = {p, QUART+p,
+        // 2 QUART+p, 3 QUART+p} slices (lane quarter q supplies k = q*QUART + p of its row / of sample column c)
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* xrow = Xs + (q * QUART) * 64 + r * 4;
+#pragma unroll
+        for (int p = 0; p < QUART; ++p) {
+            float b[4];
+            if constexpr (NT == 4) {
+                const float4 x = *(const float4*)(xrow + p * 64);
+                b[0] = x.x, b[1] = x.y, b[2] = x.z, b[3] = x.w;
+            } else if constexpr (NT == 2) {
+                const float2 x = *(const float2*)(xrow + p * 64);
+                b[0] = x.x, b[1] = x.y;
+            } else {
+                b[0] = xrow[p * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[p], b[t], acc[t], 0, 0, 0);
+        }
+        // C layout: lane (c = lane % 16, q) holds rows 4q + i (i = 0..3) of sample column t*16 + c
+        float sq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t orow = n0 + 4 * q + i;
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 16 + r;
+                const float f = (col < ns && orow < N) ? fo[orow * ns + col] : 0.0f;
+                const float d = f - acc[t][i];
+                sum += (col < ns) ? d * d : 0.0f;
+            }
+            sq[i] = lanes_allreduce<16>(sum, OpAdd());
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dsh[4 * q + i] = sq[i];
+        }
+        if (want_pen) {
+            pen += __shfl_xor(pen, 16, 64);
+            pen += __shfl_xor(pen, 32, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (q == 0 && row < N) {
+            float diff = dsh[r] / (float)ns;
+            if (want_pen) diff = diff + a.weight_penalty * (pen / (float)GS);
+            if (a.kind == 0) {
+                a.best[pidx] = diff;
+                a.result[pidx] = near;
+            } else {
+                const float b = a.best[pidx], rs = a.result[pidx];
+                const float mask = diff > b ? 1.0f : 0.0f;
+                a.best[pidx] = mask * b + (1.0f - mask) * diff;
+                a.result[pidx] = mask * rs + (1.0f - mask) * near;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // dsh and the staging buffer are rewritten by the next tile
+    }
+}
+
+// importance of scale estimation (scale_estimation.py:236-247): s per input channel, zero where the min-max
+// quantization's target is ~0, normalised per group.  16 lanes per group.
+template <typename Policy>
+__global__ __launch_bounds__(256) void k_se_importance(const float* __restrict__ w, const float* __restrict__ s, GroupArgs a,
+                                                       int64_t gs, int64_t groups_per_row, int64_t rows, float* __restrict__ imp) {
+    __shared__ float lds[kPolicyLds];
+    Policy::init_shared(lds);
+    __syncthreads();
+    const Policy pol(a, lds);
+    const int l = threadIdx.x & 15;
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = g < a.n_groups;
+    const int64_t gg = live ? g : a.n_groups - 1;
+    const typename Policy::Par par = pol.load(a, gg);
+    const float* wg = w + gg * gs;
+    // s is [batch, groups_per_row * gs]; group gg belongs to batch gg / (rows * groups_per_row), column group gg % groups_per_row
+    const float* sg = s + ((gg / (rows * groups_per_row)) * groups_per_row + gg % groups_per_row) * gs;
+    float* ig = imp + gg * gs;
+    float sum = 0.0f;
+    if (gs <= 256 && (gs & 63) == 0 && ((((uintptr_t)w | (uintptr_t)s | (uintptr_t)imp) & 15u) == 0)) {
+        // 16 lanes x float4 per 64 elements, values kept in registers between the two passes
+        float v[16];
+        const int nq = (int)(gs >> 6);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < nq) {
+                const float4 wq = *(const float4*)(wg + u * 64 + l * 4);
+                const float4 sq = *(const float4*)(sg + u * 64 + l * 4);
+                const float win[4] = {wq.x, wq.y, wq.z, wq.w}, sin[4] = {sq.x, sq.y, sq.z, sq.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int code;
+                    float val;
+                    pol.quant(win[i], par, code, val);
+                    const float target = pol.target(val, par);
+                    v[4 * u + i] = fabsf(target) <= 1e-8f ? 0.0f : sin[i];
+                    sum += v[4 * u + i];
+                }
+            }
+        }
+        sum = lanes_allreduce<16>(sum, OpAdd());
+        const float den = sum + kEps;
+        if (!live) return;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < nq)
+                *(float4*)(ig + u * 64 + l * 4) = make_float4(v[4 * u] / den, v[4 * u + 1] / den, v[4 * u + 2] / den, v[4 * u + 3] / den);
+        }
+        return;
+    }
+    for (int64_t k = l; k < gs; k += 16) {
+        int code;
+        float val;
+        pol.quant(wg[k], par, code, val);
+        const float target = pol.target(val, par);
+        const float v = fabsf(target) <= 1e-8f ? 0.0f : sg[k];
+        sum += v;
+    }
+    sum = lanes_allreduce<16>(sum, OpAdd());
+    const float den = sum + kEps;
+    if (!live) return;
+    for (int64_t k = l; k < gs; k += 16) {
+        int code;
+        float val;
+        pol.quant(wg[k], par, code, val);
+        const float target = pol.target(val, par);
+        const float v = fabsf(target) <= 1e-8f ? 0.0f : sg[k];
+        ig[k] = v / den;
+    }
+}
+
+template <typename Policy, int GS>
+static int se_step_launch(const SeStepArgs& a, int64_t batch, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)se_lds_floats<GS>() * sizeof(float);
+    static OncePerDevice attr_once;
+    if (attr_once.first_on_device() != 0) {
+        if (hipFuncSetAttribute((const void*)k_se_step<Policy, GS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_se_step<Policy, GS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_se_step<Policy, GS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+            attr_once.forget_current();
+            return launch_status("se_step attribute");
+        }
+    }
+    // blocks per group column: one resident set (one block of kSeWaves waves per CU), at most one per kSeWaves row
+    // tiles; the X slice of the group is staged once per block
+    const int64_t tile_sets = (a.rows + 16 * kSeWaves - 1) / (16 * kSeWaves);
+    int64_t per_col = (256 + a.groups * batch - 1) / (a.groups * batch);  // one resident block per CU
+    if (per_col > tile_sets) per_col = tile_sets;
+    if (per_col < 1) per_col = 1;
+    const dim3 grid((unsigned)per_col, (unsigned)a.groups, (unsigned)batch);
+    if (a.ns <= 16)
+        hipLaunchKernelGGL((k_se_step<Policy, GS, 1>), grid, dim3(kSeThreads), lds_bytes, s, a);
+    else if (a.ns <= 32)
+        hipLaunchKernelGGL((k_se_step<Policy, GS, 2>), grid, dim3(kSeThreads), lds_bytes, s, a);
+    else
+        hipLaunchKernelGGL((k_se_step<Policy, GS, 4>), grid, dim3(kSeThreads), lds_bytes, s, a);
+    return launch_status("se_step");
+}
+
+template <typename Policy>
+static int se_step_gs(const SeStepArgs& a, int64_t batch, int64_t gs, hipStream_t s) {
+    switch (gs) {
+        case 32: return se_step_launch<Policy, 32>(a, batch, s);
+        case 64: return se_step_launch<Policy, 64>(a, batch, s);
+        case 128: return se_step_launch<Policy, 128>(a, batch, s);
+        default:
+            set_error("se_step: group size %lld is not one of 32 / 64 / 128", (long long)gs);
+            return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace wc
+
+extern "C" int nncf_amd_se_step_supported(int64_t group_size, int64_t n_samples) {
+    return (group_size == 32 || group_size == 64 || group_size == 128) && n_samples >= 1 && n_samples <= 64;
+}
+
+extern "C" int nncf_amd_se_step(const float* weight, const float* importance, const float* x, const float* fp_outs,
+                                const float* scale0, const float* zero_point, float* best_diffs, float* result_scale,
+                                int64_t batch, int64_t rows, int64_t groups, int64_t group_size, int64_t n_samples,
+                                int mode, int kind, float factor, float zero_scale, float weight_penalty, void* stream) {
+    using namespace wc;
+    if (batch < 0 || rows < 0 || groups < 0 || kind < 0 || kind > 2) {
+        set_error("se_step: bad argument");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (batch * rows * groups == 0) return NNCF_AMD_OK;
+    if (!weight || !x || !fp_outs || !scale0 || !best_diffs || !result_scale || (kind != 0 && !importance)) {
+        set_error("se_step: NULL buffer");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (!nncf_amd_se_step_supported(group_size, n_samples)) {
+        set_error("se_step: group size %lld / %lld samples not supported (32, 64, 128 / 1..64)", (long long)group_size,
+                  (long long)n_samples);
+        return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+    if (groups > 65535 || batch > 65535) {
+        set_error("se_step: more than 65535 groups per row or batch entries");
+        return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+    if (((uintptr_t)weight | (uintptr_t)importance) & 15u) {
+        set_error("se_step: weight / importance must be 16-byte aligned");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    SeStepArgs a = {weight, importance, x, fp_outs, scale0, zero_point, best_diffs, result_scale, rows, groups,
+                    (int)n_samples, mode, kind, factor, zero_scale, weight_penalty};
+    hipStream_t s = (hipStream_t)stream;
+    if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
+        const bool asym = mode == NNCF_AMD_INT8_ASYM || mode == NNCF_AMD_INT4_ASYM;
+        if (asym && !zero_point) {
+            set_error("se_step: asymmetric mode needs the zero points");
+            return NNCF_AMD_ERR_BAD_ARG;
+        }
+        if (!asym) a.zp = nullptr;
+        return se_step_gs<IntPolicy>(a, batch, group_size, s);
+    }
+    a.zp = nullptr;
+    if (mode == NNCF_AMD_NF4) return se_step_gs<FloatPolicy<true>>(a, batch, group_size, s);
+    if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) return se_step_gs<FloatPolicy<false>>(a, batch, group_size, s);
+    set_error("se_step: unsupported mode %d", mode);
+    return NNCF_AMD_ERR_MODE;
+}
+
+extern "C" int nncf_amd_se_importance(const float* weight, const float* s_per_channel, const float* scale0,
+                                      const float* zero_point, int64_t batch, int64_t rows, int64_t groups,
+                                      int64_t group_size, int mode, float* importance, void* stream) {
+    using namespace wc;
+    if (batch < 0 || rows < 0 || groups < 0 || group_size < 1) {
+        set_error("se_importance: bad argument");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    const int64_t n_groups = batch * rows * groups;
+    if (n_groups == 0) return NNCF_AMD_OK;
+    if (!weight || !s_per_channel || !scale0 || !importance) {
+        set_error("se_importance: NULL buffer");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    GroupArgs a = {};
+    a.scale_in = scale0;
+    a.zp_in = zero_point;
+    a.zp_dtype = NNCF_AMD_ZP_F32;
+    a.n_groups = n_groups;
+    a.gs = group_size;
+    a.inner = 1;
+    a.mode = mode;
+    const dim3 grid((unsigned)((n_groups * 16 + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
+        const bool asym = mode == NNCF_AMD_INT8_ASYM || mode == NNCF_AMD_INT4_ASYM;
+        if (asym && !zero_point) {
+            set_error("se_importance: asymmetric mode needs the zero points");
+            return NNCF_AMD_ERR_BAD_ARG;
+        }
+        if (!asym) a.zp_in = nullptr;
+        hipLaunchKernelGGL((k_se_importance<IntPolicy>), grid, dim3(256), 0, st, weight, s_per_channel, a, group_size, groups, rows, importance);
+    } else if (mode == NNCF_AMD_NF4) {
+        a.zp_in = nullptr;
+        hipLaunchKernelGGL((k_se_importance<FloatPolicy<true>>), grid, dim3(256), 0, st, weight, s_per_channel, a, group_size, groups, rows, importance);
+    } else if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) {
+        a.zp_in = nullptr;
+        hipLaunchKernelGGL((k_se_importance<FloatPolicy<false>>), grid, dim3(256), 0, st, weight, s_per_channel, a, group_size, groups, rows, importance);
+    } else {
+        set_error("se_importance: unsupported mode %d", mode);
+        return NNCF_AMD_ERR_MODE;
+    }
+    return launch_status("se_importance");
+}

@@ -66,6 +66,13 @@ def calculate_quantization_params(
     cur_config = deepcopy(config)
     cur_config.group_size = group_size
 
+    fused = (FUSED_SEARCH and weight.ndim in (2, 3) and reduction_axis == weight.ndim - 1 and weight.numel() > 0
+             and bool(_lib.lib().nncf_amd_se_step_supported(group_size, X.shape[-1])))
+    if fused:
+        result_scale, zp = _fused_search(weight.contiguous(), s, X, config, group_size, initial_steps, scale_steps,
+                                         weight_penalty)
+        return _finish(result_scale, zp, config, was_transposed)
+
     if not config.is_integer:
         q_weights, compressed_weight = float_quantize_dequantize_weight(weight, cur_config, reduction_axis,
                                                                          return_compressed_weight=True)
@@ -152,6 +159,11 @@ def calculate_quantization_params(
         mask = mask.unsqueeze(-1)
         result_scale = mask * result_scale + (1.0 - mask) * near_to_ideal_scale
 
+    return _finish(result_scale, zp, config, was_transposed)
+
+
+def _finish(result_scale, zp, config, was_transposed):
+    """scale_estimation.py:362-377: shapes of the returned parameters."""
     if config.group_size == -1:
         result_scale = result_scale.squeeze(-2)
         if zp is not None:
@@ -166,6 +178,54 @@ def calculate_quantization_params(
             if zp is not None:
                 zp = torch.movedim(zp, (-1, -2, -3), (-2, -3, -1))
     return result_scale, zp
+
+
+FUSED_SEARCH = True  # developer switch: False takes the step-by-step path below the fused one for every shape
+
+
+def _fused_search(weight, s, X, config, group_size, initial_steps, scale_steps, weight_penalty):
+    """The search of scale_estimation.py:236-360 with ONE launch per candidate (nncf_amd_se_step): the weight and the
+    importance are read once per step, nothing weight-sized is written.  weight: fp32 contiguous [(E,) N, K] reduced
+    along the last axis; s: [(E,) K]; X: [(E,) K, n].  Returns (result_scale [(E,) N, G, 1], zp fp32 | None)."""
+    from nncf_amd.weight_lowering import calculate_float_quantization_params, calculate_integer_quantization_params
+
+    lib = _lib.lib()
+    dev = weight.device
+    batch = weight.shape[0] if weight.ndim == 3 else 1
+    N, K = weight.shape[-2], weight.shape[-1]
+    G = K // group_size
+    wg, axis = reshape_weight_for_grouped_quantization(weight, weight.ndim - 1, group_size)  # [(E,) N, G, gs] view
+    unit = WeightCompressionConfig(mode=config.mode, group_size=-1)
+    if config.is_integer:
+        scale0, zp_i = calculate_integer_quantization_params(wg, (axis,), unit)
+        zp = zp_i.to(torch.float32) if zp_i is not None else None  # scale_estimation.py:227-229
+    else:
+        scale0, zp = calculate_float_quantization_params(wg, (axis,), unit), None
+    s = s.to(torch.float32).contiguous()
+    Xg, _ = reshape_weight_for_grouped_quantization(X, -2, group_size)  # [(E,) G, gs, n]
+    Xg = Xg.contiguous()
+    n_s = Xg.shape[-1]
+    fp_outs = torch.matmul(torch.movedim(wg, -2, -3), Xg).contiguous()  # [(E,) G, N, n]  (:250)
+    importance = torch.empty_like(wg)
+    best = torch.empty(scale0.shape, dtype=torch.float32, device=dev)
+    result = torch.empty_like(best)
+    mode_id = _lib.MODE_ID[config.mode.value]
+    with torch.cuda.device(dev):
+        stream = _lib.stream_of(weight)
+        _lib.check(lib.nncf_amd_se_importance(_lib.ptr(wg), _lib.ptr(s), _lib.ptr(scale0), _lib.ptr(zp), batch, N, G,
+                                              group_size, mode_id, _lib.ptr(importance), stream))
+
+        def step(kind, factor=1.0):
+            _lib.check(lib.nncf_amd_se_step(_lib.ptr(wg), _lib.ptr(importance), _lib.ptr(Xg), _lib.ptr(fp_outs),
+                                            _lib.ptr(scale0), _lib.ptr(zp), _lib.ptr(best), _lib.ptr(result), batch, N, G,
+                                            group_size, n_s, mode_id, kind, factor, 0.001, weight_penalty, stream))
+
+        step(0)  # min-max baseline: best_diffs, result_scale = scale0
+        for _ in range(initial_steps):
+            step(1)  # candidate = current result_scale
+        for scale_step in range(scale_steps):
+            step(2, 1.0 - 0.05 * scale_step)  # candidate = factor * scale0
+    return result, zp
 
 
 class ScaleEstimation:

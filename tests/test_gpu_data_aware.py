@@ -257,6 +257,67 @@ def test_se_estimate_matches_the_unfused_chain(mode, gs):
     np.testing.assert_allclose(host(out), host(ref), rtol=2e-6, atol=1e-7)
 
 
+def _se_case(shape, n_samples, seed, device="cuda"):
+    """Weight + per-sample token means with outlier channels (what WCTensorStatistic carries)."""
+    from nncf_amd.statistics import WCTensorStatistic
+    g = torch.Generator(device=device).manual_seed(seed)
+    w = torch.randn(*shape, device=device, generator=g) * 0.05
+    K = shape[-1]
+    lead = tuple(shape[:-2])  # expert axis of a 3-D weight
+    means = []
+    for _ in range(n_samples):
+        m = torch.randn(*lead, K, device=device, generator=g)
+        m[..., ::61] *= 12.0
+        means.append(m)
+    shapes = [lead + (7 + 3 * i, K) for i in range(n_samples)]
+    return w, WCTensorStatistic(means, shapes)
+
+
+@pytest.mark.parametrize("shape,gs,n_samples,subset", [((96, 256), 32, 8, 8), ((200, 512), 64, 40, 32), ((130, 384), 128, 70, 64),
+                                                        ((64, 128), -1, 5, 32), ((3, 70, 256), 64, 33, 64)])
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym", "nf4", "mxfp4", "int8_asym"])
+def test_fused_se_search_matches_oracle(mode, shape, gs, n_samples, subset):
+    """The fused search (nncf_amd_se_step: one launch per candidate scale) against the oracle's restatement of
+    scale_estimation.py:160-377 on the same statistics: scales <= 1e-5 on >= 99.5 % of the groups (a candidate whose
+    output error ties with the best one within fp32 summation noise may go either way; the reference's numpy and
+    torch backends differ from each other in the same way), zero points equal.  Row counts that are not multiples of
+    the 32-row MFMA tile, 1 and 2 sample tiles, a 3-D (MoE) weight."""
+    from nncf_amd import scale_estimation as SE
+    w, stats = _se_case(shape, n_samples, seed=len(shape) * 100 + n_samples)
+    axes = (len(shape) - 1,)
+    sc, zp = SE.calculate_quantization_params(stats, w, axes, _cfg(mode, gs), -1, subset, 4, 5)
+    ref_s, ref_z = O.scale_estimation_params([host(m) for m in stats.mean_values], stats.shape_values, host(w), axes,
+                                             mode, gs, -1, subset, 4, 5)
+    assert tuple(sc.shape) == ref_s.shape
+    close = np.isclose(host(sc), ref_s, rtol=1e-5, atol=0)
+    assert close.mean() >= 0.995, close.mean()
+    if ref_z is None:
+        assert zp is None
+    else:
+        assert np.array_equal(host(zp), ref_z)
+
+
+@pytest.mark.parametrize("penalty", [-1.0, 0.3])
+@pytest.mark.parametrize("mode,gs", [("int4_asym", 128), ("int4_sym", 64), ("nf4", 32)])
+def test_fused_se_search_equals_stepwise_path(mode, gs, penalty):
+    """Fused search == the step-by-step path (estimate kernel + QDQ + torch.matmul + blends) on a Llama-sized row
+    count, including the weight-penalty term; the two sum the output error in different orders, hence 1e-5 / 99.9 %."""
+    from nncf_amd import scale_estimation as SE
+    w, stats = _se_case((1000, 1024), 64, seed=3)
+    cfg = _cfg(mode, gs)
+    a_s, a_z = SE.calculate_quantization_params(stats, w, (1,), cfg, -1, 64, 5, 5, penalty)
+    SE.FUSED_SEARCH = False
+    try:
+        b_s, b_z = SE.calculate_quantization_params(stats, w, (1,), cfg, -1, 64, 5, 5, penalty)
+    finally:
+        SE.FUSED_SEARCH = True
+    assert a_s.shape == b_s.shape
+    close = torch.isclose(a_s, b_s, rtol=1e-5, atol=0).float().mean()
+    assert float(close) >= 0.999, float(close)
+    if b_z is not None:
+        assert torch.equal(a_z, b_z)
+
+
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 63, 64, 65, 100, 127, 128])
 def test_cholinv_block_kernel(n):
     """nncf_amd_cholinv_block (one workgroup, n <= 128) vs fp64 cholesky + triangular inverse: the block is a
