@@ -7,9 +7,12 @@ bench.py -- throughput of the weight-compression lowering hot path on MI355X.
 A "step" is one pass of the fused lowering (group min/max -> scale -> round -> nibble pack) over every linear
 weight of a Llama-3-8B-shaped model (7 shapes x 32 layers, bf16, random init, resident in HBM), INT4_SYM
 group_size=128, through the C ABI (nncf_amd_int_quantize_batched).  Metric: GB/s of bf16 weights compressed
-(input bytes / wall time), whole job.  N > 1: one process per GPU (torchrun), every rank compresses its own
-model-sized shard of layers, no data-path collective (weak scaling; --gather adds the RCCL all-gather of the
-compressed payload and reports it separately).
+(input bytes of the WHOLE model / wall time of the slowest rank).  N > 1: one process per GPU (torchrun); the
+model's tensor list is cut by longest-processing-time-first (nncf_amd.distributed.partition_lpt, the partition the
+product uses), every rank creates and compresses ONLY its shard, no data-path collective: strong scaling of one
+model ("wall time of Llama-3-8B / 70B at 1/2/4/8 GPUs" = ms_per_step).  --gather adds the RCCL all-gather that
+assembles the compressed payload on every rank and reports it separately; --scaling weak gives every rank a whole
+model of its own instead (round-1 behaviour).
 
 Prints ONE JSON line on rank 0.
 """
@@ -59,36 +62,34 @@ def algorithmic_bytes_per_elem(mode, gs, cols):
 class Job:
     """One rank's resident weights + preallocated outputs + C-ABI descriptor arrays."""
 
-    def __init__(self, geometry, mode, gs, device, layers=None, seed=0):
+    def __init__(self, tensors, mode, gs, device, seed=0):
+        """tensors: [(global index, (out, in)), ...] = this rank's shard of the model's tensor list."""
         import ctypes
 
         from nncf_amd import _lib
 
         self._lib, self._ct = _lib, ctypes
-        shapes, n_layers = SHAPES[geometry]
-        n_layers = layers or n_layers
         self.mode, self.gs, self.device = mode, gs, device
         self.is_int = mode.startswith("int")
         four = not mode.startswith("int8")
         self.weights, self.outs, self.scales, self.zps = [], [], [], []
         gen = torch.Generator(device=device)
-        for layer in range(n_layers):
-            gen.manual_seed(seed * 100003 + layer)
-            for (o, i) in shapes:
-                w = (torch.randn(o, i, device=device, generator=gen, dtype=torch.float32) * 0.02).to(torch.bfloat16)
-                g = gs if gs != -1 else i
-                self.weights.append(w)
-                self.outs.append(torch.empty(o * i // 2 if four else o * i, dtype=torch.uint8, device=device))
-                self.scales.append(torch.empty(o * (i // g), dtype=torch.float32, device=device))
-                self.zps.append(torch.empty(o * (i // g), dtype=torch.int32, device=device)
-                                if mode.endswith("asym") else None)
+        for index, (o, i) in tensors:
+            gen.manual_seed(seed * 100003 + index)  # a tensor's values depend on its index, not on who owns it
+            w = (torch.randn(o, i, device=device, generator=gen, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+            g = gs if gs != -1 else i
+            self.weights.append(w)
+            self.outs.append(torch.empty(o * i // 2 if four else o * i, dtype=torch.uint8, device=device))
+            self.scales.append(torch.empty(o * (i // g), dtype=torch.float32, device=device))
+            self.zps.append(torch.empty(o * (i // g), dtype=torch.int32, device=device)
+                            if mode.endswith("asym") else None)
         n = len(self.weights)
         self.n = n
         self.elems = sum(w.numel() for w in self.weights)
         self.in_bytes = 2 * self.elems
         self.alg_bytes = sum(w.numel() * algorithmic_bytes_per_elem(mode, gs, w.shape[1]) for w in self.weights)
-        VP = ctypes.c_void_p * n
-        I64 = ctypes.c_int64 * n
+        VP = ctypes.c_void_p * max(n, 1)
+        I64 = ctypes.c_int64 * max(n, 1)
         self.c_w = VP(*[w.data_ptr() for w in self.weights])
         self.c_rows = I64(*[w.shape[0] for w in self.weights])
         self.c_cols = I64(*[w.shape[1] for w in self.weights])
@@ -98,6 +99,8 @@ class Job:
         self.stream = torch.cuda.current_stream(device)
 
     def step(self):
+        if self.n == 0:
+            return
         L, ct = self._lib.lib(), self._ct
         s = ct.c_void_p(self.stream.cuda_stream)
         if self.is_int:
@@ -113,29 +116,38 @@ class Job:
 
 
 def cpu_baseline(geometry, mode, gs, budget_s=12.0):
-    """The reference's torch-CPU op chain (oracle/torch_chain.py, a port) on the host cores, bounded sample."""
-    from oracle.torch_chain import compress_int_torch
+    """The reference's torch-CPU op chain (oracle/torch_chain.py, a port) on the host cores, bounded sample.
+    Threads: the box's CPU share for one GPU (OMP_NUM_THREADS, 16 on the pool's boxes; os.cpu_count() there shows the
+    whole machine and is reported next to it)."""
+    from oracle.torch_chain import compress_float_torch, compress_int_torch
 
-    if not mode.startswith("int"):
-        return None
     shapes, _ = SHAPES[geometry]
-    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    shapes = shapes[:7]
+    visible = os.cpu_count() or 1
+    threads = max(1, min(visible, int(os.environ.get("OMP_NUM_THREADS", "16"))))
     torch.set_num_threads(threads)
+    if mode.startswith("int"):
+        fn, what = (lambda w: compress_int_torch(w, mode, gs, pack=True)), "reference torch-CPU op chain + pack_int4"
+    else:
+        fn, what = (lambda w: compress_float_torch(w, mode, gs)), "reference torch-CPU op chain (fp32 quantile values, no packing: the reference's torch path has none)"
     gen = torch.Generator().manual_seed(0)
     ws = [(torch.randn(o, i, generator=gen) * 0.02).to(torch.bfloat16) for (o, i) in shapes]
     for w in ws[:2]:
-        compress_int_torch(w, mode, gs, pack=True)  # warm-up (thread pool, allocator)
+        fn(w)  # warm-up (thread pool, allocator)
     done_bytes, t_total, passes = 0, 0.0, 0
     while t_total < budget_s and passes < 200:
         for w in ws:
             t0 = time.perf_counter()
-            compress_int_torch(w, mode, gs, pack=True)
+            fn(w)
             t_total += time.perf_counter() - t0
             done_bytes += 2 * w.numel()
+            if t_total > 2.5 * budget_s:
+                break
         passes += 1
-    return {"value": round(done_bytes / t_total / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
-            "sample": f"reference torch-CPU op chain + pack_int4 (oracle/torch_chain.py) on the {len(ws)} tensors of one "
-                      f"{geometry} layer, bf16, {mode} g{gs}, {passes} passes, {t_total:.1f}s of CPU work"}
+    return {"value": round(done_bytes / t_total / 1e9, 4), "unit": "GB/s", "cores": threads, "host_cpus_visible": visible,
+            "kind": "port",
+            "sample": f"{what} (oracle/torch_chain.py) on the {len(ws)} tensors of one {geometry} layer, bf16, {mode} "
+                      f"g{gs}, {passes} passes, {t_total:.1f}s of CPU work on {threads} threads"}
 
 
 def main():
@@ -146,6 +158,8 @@ def main():
     ap.add_argument("--workload", default="llama3-8b-int4sym-g128", choices=sorted(WORKLOADS))
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug)")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all-gather of the compressed payload")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: ONE model sharded over the ranks (default); weak: a whole model per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -157,14 +171,34 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
+    # one GPU per rank is the real thing (RCCL).  With fewer GPUs than ranks (rehearsal of the N > 1 code path on a
+    # one-GPU box) the ranks share the cards and synchronise over gloo; such a run is marked in the JSON line.
+    n_dev = torch.cuda.device_count()
+    rehearsal = world > 1 and n_dev < world
+    device = torch.device("cuda", local_rank % max(n_dev, 1))
     torch.cuda.set_device(device)
+    if world > 1:
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    coll_dev = torch.device("cpu") if rehearsal else device
 
     geometry, mode, gs = WORKLOADS[args.workload]
-    job = Job(geometry, mode, gs, device, layers=args.layers or None, seed=rank)
+    shapes, n_layers = SHAPES[geometry]
+    n_layers = args.layers or n_layers
+    model = [(layer * len(shapes) + j, sh) for layer in range(n_layers) for j, sh in enumerate(shapes)]
+    model_elems = sum(o * i for _, (o, i) in model)
+    if args.scaling == "strong" and world > 1:
+        from nncf_amd.distributed import partition_lpt
+
+        mine = sorted(partition_lpt([o * i for _, (o, i) in model], world)[rank])
+        job = Job([model[k] for k in mine], mode, gs, device, seed=0)
+    else:
+        job = Job(model, mode, gs, device, seed=rank)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -178,7 +212,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -194,9 +228,14 @@ def main():
     dev_ms_per_step = ev0.elapsed_time(ev1) / ev_steps
 
     gather_ms = None
-    if args.gather and dist is not None:
-        payload = torch.cat([t.view(torch.uint8) for t in job.outs] + [t.view(torch.uint8) for t in job.scales])
-        out = torch.empty(world * payload.numel(), dtype=torch.uint8, device=device)
+    if args.gather and dist is not None and not rehearsal:
+        payload = torch.cat([t.view(torch.uint8) for t in job.outs] + [t.view(torch.uint8) for t in job.scales]
+                            + [t.view(torch.uint8) for t in job.zps if t is not None])
+        size = torch.tensor([payload.numel()], device=device, dtype=torch.int64)
+        dist.all_reduce(size, op=dist.ReduceOp.MAX)  # shards differ by a few tensors: pad to the longest
+        pad = (int(size.item()) + 15) // 16 * 16
+        payload = torch.cat([payload, torch.zeros(pad - payload.numel(), dtype=torch.uint8, device=device)])
+        out = torch.empty(world * pad, dtype=torch.uint8, device=device)
         barrier()
         t1 = time.perf_counter()
         dist.all_gather_into_tensor(out, payload)
@@ -205,9 +244,10 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        total_in_bytes = job.in_bytes * world
+        strong = args.scaling == "strong"
+        total_in_bytes = 2 * model_elems if strong else job.in_bytes * world
         value = total_in_bytes / (elapsed / args.steps) / 1e9
-        achieved = job.alg_bytes / (dev_ms_per_step * 1e-3) / 1e9
+        achieved = job.alg_bytes / (dev_ms_per_step * 1e-3) / 1e9  # rank 0's shard on rank 0's GPU
         if gs != -1:  # grouped modes: multi-tensor tile kernel, launches of <= 48 tensors
             launches = -(-job.n // 48)
             kernel = "wc::k_grouped_batch<%s, bf16, VPG=%d>" % (
@@ -219,12 +259,17 @@ def main():
                 per_class[w.shape[1]] = per_class.get(w.shape[1], 0) + 1
             launches = sum(-(-c // 48) for c in per_class.values())
             kernel = "wc::k_rows_batch<IntPolicyT<%s>, bf16> (%d row-length classes)" % (mode.upper(), len(per_class))
-        traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json), same command
-            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
-                traffic = json.load(fh).get(args.workload, {}).get("traffic_bytes_per_launch")
-            if traffic is not None and (args.layers or world != 1):
-                traffic = None
+        # HBM bytes per launch: NOT measured by this run.  The figure is read from the committed rocprofv3 --pmc passes
+        # of this same command (profiles/r2_traffic.json, made by tools/traffic_from_pmc.py) and labelled as such;
+        # null for any other shape of run.
+        traffic, traffic_source = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as fh:
+                entry = json.load(fh).get(args.workload, {})
+            if not args.layers and world == 1 and entry.get("traffic_bytes_per_launch") is not None:
+                traffic = entry["traffic_bytes_per_launch"]
+                traffic_source = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                                 "committed; not re-measured by this run)"
         except OSError:
             pass
         res = {
@@ -236,21 +281,27 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{geometry}-shaped linears x{len(job.weights) // len(SHAPES[geometry][0])} layers, "
+            "config": {"workload": f"{geometry}-shaped linears x{n_layers} layers, "
                                    f"bf16 random-init, {mode} group_size={gs}, fused quantize+pack, data-free RTN",
-                       "tensors_per_step": job.n, "elements_per_step_per_gpu": job.elems,
-                       "partition": "each rank compresses its own model-sized set of layers; no collective"},
+                       "tensors_in_model": len(model), "elements_in_model": model_elems,
+                       "tensors_on_rank0": job.n, "elements_on_rank0": job.elems,
+                       "partition": ("ONE model: tensor list cut by LPT over the ranks, each rank holds and compresses "
+                                     "only its shard; no data-path collective") if strong else
+                                    "each rank compresses its own whole model; no collective"},
+            "model_wall_ms": round(ms_per_step, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "launches_per_step": launches,
-                         "avg_launch_us": round(dev_ms_per_step * 1e3 / launches, 3),
-                         "algorithmic_bytes_per_launch": round(job.alg_bytes / launches, 1),
+                         "avg_launch_us": round(dev_ms_per_step * 1e3 / max(launches, 1), 3),
+                         "algorithmic_bytes_per_launch": round(job.alg_bytes / max(launches, 1), 1),
                          "device_ms_per_step": round(dev_ms_per_step, 4)},
         }
+        if rehearsal:
+            res["rehearsal"] = f"{world} ranks share {n_dev} GPU(s), gloo barrier: exercises the sharded code path, not a scaling number"
         if gather_ms is not None:
             res["allgather_ms"] = round(gather_ms, 3)
         if not args.no_cpu_baseline and world == 1:

@@ -137,3 +137,128 @@ def all_gather_sample_statistics(local: Sequence[torch.Tensor], n_samples: int, 
     recv = torch.empty((world * per_rank,) + shape, dtype=dtype, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
     return [recv[(i % world) * per_rank + i // world] for i in range(n_samples)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Layer-sharded data-aware compression (BASELINE configs[3]: GPTQ with layers sharded across the GPUs of a node,
+# configs[2]: AWQ / scale estimation).  The unit of work is what shares one activation: the Linears that read it have
+# ONE Hessian / one set of statistics (gptq.py:118-171 walks nodes one by one; q/k/v and gate/up see the same input).
+# Units are independent given their activations, so they are spread by LPT on an operation count and every rank
+# loads / streams only the activations of the units it owns.  Nothing is reduced across ranks (Hessians stay on their
+# owner); the only exchange is the final all-gather of packed codes + scales (+ zero points).
+def run_sharded(costs: Sequence[float], work_fn, gather: bool = True, group=None) -> Dict:
+    """costs[i] = relative cost of unit i (same list on every rank); work_fn(i) -> {key: tuple of tensors / None}
+    is called on the owner of unit i only.  Returns the union of all ranks' dictionaries (gather=True) or this
+    rank's own.  Keys must be unique across units and picklable; one all_gather_object of metadata (keys, shapes,
+    dtypes) + ONE all_gather_into_tensor of the padded flat payload."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    scale = max([float(c) for c in costs] + [1.0])
+    parts = partition_lpt([int(float(c) / scale * (1 << 40)) + 1 for c in costs], world)
+    local: Dict = {}
+    for i in parts[rank]:
+        for key, val in work_fn(i).items():
+            if key in local:
+                raise ValueError(f"run_sharded: key {key!r} returned twice")
+            local[key] = tuple(val)
+    if not gather or world == 1:
+        return local
+    keys = list(local)
+    meta = [(k, [None if t is None else (tuple(t.shape), t.dtype) for t in local[k]]) for k in keys]
+    all_meta: List = [None] * world
+    dist.all_gather_object(all_meta, meta, group=group)
+    flat = [t for k in keys for t in local[k] if t is not None]
+    specs = [[sd for _, slots in m for sd in slots if sd is not None] for m in all_meta]
+    if not flat:  # this rank owns nothing: it still takes part in the collective, on the device the others use
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        flat = [torch.empty(0, dtype=torch.uint8, device=dev)]
+        specs[rank] = [((0,), torch.uint8)]
+    gathered = all_gather_payloads(flat, specs, group=group)
+    out: Dict = {}
+    for r in range(world):
+        it = iter(gathered[r])
+        for k, slots in all_meta[r]:
+            out[k] = tuple(None if sd is None else next(it) for sd in slots)
+    return out
+
+
+def gptq_unit_cost(k: int, tokens: int, out_features: Sequence[int]) -> float:
+    """Operation count of one GPTQ unit: Hessian K^2 T (symmetric half, MFMA), Cholesky-with-inverse (2/3) K^3, and
+    per weight the column sweep + trailing updates N K^2."""
+    return float(k) * k * tokens + (2.0 / 3.0) * float(k) ** 3 + sum(float(n) * k * k for n in out_features)
+
+
+def gptq_sharded(units, config, load_unit, gather: bool = True, group=None, damp_percent: float = 0.1,
+                 block_size: int = 128, backend=None) -> Dict:
+    """GPTQ over a list of units, layer-sharded (gptq.py:82-171 without the cross-layer replay: every unit comes with
+    its own activations, as in BASELINE configs[3]'s synthetic calibration set).
+      units[i] = {"k": K, "tokens": T, "weights": [(name, out_features), ...]}   -- the same list on every rank
+      load_unit(i) -> (activations: list of [.., T_j, K] tensors, weights: {name: [N, K] tensor}) on the owner only
+    Returns {name: (packed codes uint8, scale fp32, zero point int32 | None)}.
+    `backend` (test hook) supplies calculate_hessian / prepare_hinv / quantize_weights / pack."""
+    from nncf_amd.parameters import CompressedWeight, as_config
+
+    config = as_config(config)
+    if backend is None:
+        from nncf_amd import gptq as _gptq, weight_lowering as _wl
+
+        class backend:  # noqa: N801
+            calculate_hessian = staticmethod(lambda xs: _gptq.calculate_hessian(xs)[0])
+            prepare_hinv = staticmethod(_gptq.prepare_hinv)
+
+            @staticmethod
+            def quantize_weights(w32, hinv, dead):
+                return _gptq.quantize_weights(None, w32, config, hinv=hinv, dead=dead, damp_percent=damp_percent,
+                                              block_size=block_size)
+
+            @staticmethod
+            def pack(q, scale, zp, dtype):
+                cw = _wl.compress_weight_packed(q.to(dtype), (1,), config, CompressedWeight(None, scale, zp))
+                return cw.tensor
+
+    costs = [gptq_unit_cost(u["k"], u["tokens"], [n for _, n in u["weights"]]) for u in units]
+
+    def work(i):
+        xs, ws = load_unit(i)
+        hessian = backend.calculate_hessian(xs)
+        del xs
+        hinv, dead = backend.prepare_hinv(hessian, damp_percent)
+        del hessian
+        out = {}
+        for name, _ in units[i]["weights"]:
+            w = ws[name]
+            q, scale, zp = backend.quantize_weights(w.to(torch.float32).contiguous(), hinv, dead)
+            out[name] = (backend.pack(q, scale, zp, w.dtype), scale, zp)
+        return out
+
+    return run_sharded(costs, work, gather=gather, group=group)
+
+
+def scale_estimation_sharded(items, config, load_item, gather: bool = True, group=None, subset_size: int = 64,
+                             initial_steps: int = 5, scale_steps: int = 5, backend=None) -> Dict:
+    """Scale estimation (+ lowering with the estimated parameters) over independent weights, sharded by LPT on the
+    element count (scale_estimation.py:97-158 walks the weights one by one; each needs only its own statistics).
+      items[i] = (name, (out_features, in_features));  load_item(i) -> (weight [N, K], WCTensorStatistic) on the owner
+    Returns {name: (packed codes, scale fp32, zero point | None)}."""
+    from nncf_amd.parameters import CompressedWeight, as_config
+
+    config = as_config(config)
+    if backend is None:
+        from nncf_amd import scale_estimation as _se, weight_lowering as _wl
+
+        class backend:  # noqa: N801
+            @staticmethod
+            def estimate(w, stats):
+                return _se.calculate_quantization_params(stats, w, (1,), config, -1, subset_size, initial_steps, scale_steps)
+
+            @staticmethod
+            def pack(w, scale, zp):
+                cw = _wl.compress_weight_packed(w, (1,), config, CompressedWeight(None, scale, zp))
+                return cw.tensor, cw.scale, cw.zero_point
+
+    def work(i):
+        name = items[i][0]
+        w, stats = load_item(i)
+        scale, zp = backend.estimate(w, stats)
+        return {name: backend.pack(w, scale, zp)}
+
+    return run_sharded([a * b for _, (a, b) in items], work, gather=gather, group=group)

@@ -54,3 +54,39 @@ def compress_int_torch(weight: torch.Tensor, mode: str, group_size: int, pack: b
         t = t.contiguous().reshape(-1, 2)
         cw = torch.bitwise_and(t[..., ::2], 15) | t[..., 1::2] << 4
     return cw, scale, zero_point
+
+
+def compress_float_torch(weight: torch.Tensor, mode: str, group_size: int):
+    """NF4 / MXFP4 torch-CPU op chain (weight_lowering.py:84-128 scale, :613-626 normalise, :557-586 nearest quantile
+    with the e2m1 tie rule).  Returns (fp32 quantile values, scale) like the reference's torch path does (:585-586).
+    Checked against oracle/wc_oracle.py in tests/test_abi_cpu.py."""
+    from oracle import wc_oracle as O
+
+    w = weight
+    if group_size != -1:
+        if w.shape[1] % group_size != 0:
+            raise ValueError(f"Channel size {w.shape[1]} should be divisible by size of group {group_size}.")
+        w = w.reshape(w.shape[0], w.shape[1] // group_size, group_size)
+    if w.dtype != torch.float32:
+        w = w.to(torch.float32)
+    nf4 = mode == "nf4"
+    scale = torch.amax(torch.abs(w), dim=w.ndim - 1, keepdim=True)
+    if not nf4:
+        scale = scale / 6.0
+    scale = torch.where(torch.abs(scale) < EPS, EPS, scale)
+    if mode == "mxfp4":
+        scale = torch.log2(scale)
+        scale = torch.ceil(scale)
+        scale = torch.clip(scale, -127, 127)
+        scale = 2 ** scale
+    norm = w / scale
+    quantiles = torch.from_numpy(O.NF4_QUANTILES if nf4 else O.F4E2M1_QUANTILES)
+    centers = torch.from_numpy(O.CENTER_OF_NF4_QUANTILES if nf4 else O.CENTER_OF_F4E2M1_QUANTILES)
+    idx = torch.searchsorted(centers, norm)
+    if not nf4:
+        shifted = torch.clip(idx + 1, 0, quantiles.numel() - 1)
+        dist_left = torch.abs(norm - quantiles[idx])
+        dist_right = torch.abs(norm - quantiles[shifted])
+        right = (dist_right < dist_left) | ((dist_left == dist_right) & ((shifted + 1) % 2 == 0))
+        idx = torch.where(right, shifted, idx)
+    return quantiles[idx], scale

@@ -89,3 +89,128 @@ def test_two_rank_gloo_all_gather():
     for p in procs:
         p.join(30)
     assert results == {0: True, 1: True}
+
+
+# ----------------------------------------------------------------------------------------------------- data-aware
+def _oracle_gptq_backend(mode, gs, loaded):
+    """torch / numpy stand-ins for the HIP-only GPTQ steps (test-only): the oracle does the arithmetic."""
+    from oracle import wc_oracle as O
+
+    class backend:  # noqa: N801
+        @staticmethod
+        def calculate_hessian(xs):
+            return torch.from_numpy(O.gptq_hessian([x.numpy() for x in xs])[0])
+
+        @staticmethod
+        def prepare_hinv(hessian, damp):
+            hinv, dead = O.gptq_hinv(hessian.numpy().copy(), damp)
+            return torch.from_numpy(hinv), torch.from_numpy(dead)
+
+        @staticmethod
+        def quantize_weights(w32, hinv, dead):
+            q, s, z = O.gptq_quantize_weights(None, w32.numpy().copy(), mode, gs, hinv=hinv.numpy(), dead=dead.numpy())
+            return torch.from_numpy(q), torch.from_numpy(s), None if z is None else torch.from_numpy(z)
+
+        @staticmethod
+        def pack(q, scale, zp, dtype):
+            codes, _, _ = O.do_integer_quantization(q.numpy(), mode, gs, (1,), scale.numpy(), None if zp is None else zp.numpy())
+            return torch.from_numpy(O.pack_uint4(codes) if zp is not None else O.pack_int4(codes))
+
+    return backend
+
+
+def _gptq_case():
+    rng = np.random.default_rng(7)
+    units = [{"k": 64, "tokens": 40, "weights": [("l0.q", 16), ("l0.k", 8)]},
+             {"k": 32, "tokens": 24, "weights": [("l0.o", 16)]},
+             {"k": 64, "tokens": 40, "weights": [("l1.gate", 24), ("l1.up", 24)]},
+             {"k": 96, "tokens": 30, "weights": [("l1.down", 8)]}]
+    data = []
+    for u in units:
+        xs = [torch.from_numpy(rng.standard_normal((1, u["tokens"] // 2, u["k"])).astype(np.float32)) for _ in range(2)]
+        ws = {n: torch.from_numpy((rng.standard_normal((o, u["k"])) * 0.05).astype(np.float32)) for n, o in u["weights"]}
+        data.append((xs, ws))
+    return units, data
+
+
+def _worker_data_aware(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nncf_amd.distributed import gptq_sharded, gptq_unit_cost, partition_lpt, run_sharded, scale_estimation_sharded
+        from nncf_amd.parameters import WeightCompressionConfig
+        from oracle import wc_oracle as O
+
+        mode, gs = "int4_asym", 32
+        units, data = _gptq_case()
+        loaded = []
+
+        def load_unit(i):
+            loaded.append(i)
+            return data[i]
+
+        res = gptq_sharded(units, WeightCompressionConfig(mode, gs), load_unit, backend=_oracle_gptq_backend(mode, gs, loaded))
+        costs = [gptq_unit_cost(u["k"], u["tokens"], [n for _, n in u["weights"]]) for u in units]
+        ok = sorted(loaded) == sorted(partition_lpt([int(c) for c in costs], world)[rank]) and 0 < len(loaded) < len(units)
+        names = [n for u in units for n, _ in u["weights"]]
+        ok = ok and sorted(res) == sorted(names)
+        # every rank now holds every weight's payload, equal to a single-process run of the same chain
+        bk = _oracle_gptq_backend(mode, gs, [])
+        for u, (xs, ws) in zip(units, data):
+            hinv, dead = bk.prepare_hinv(bk.calculate_hessian(xs), 0.1)
+            for n, _ in u["weights"]:
+                qw, sc, zp = bk.quantize_weights(ws[n].clone(), hinv, dead)
+                packed = bk.pack(qw, sc, zp, torch.float32)
+                ok = ok and torch.equal(res[n][0], packed) and torch.equal(res[n][1], sc) and torch.equal(res[n][2], zp)
+        # scale estimation, sharded per weight; one item only: rank 1 owns nothing and still joins the collective
+        from nncf_amd.statistics import WCTensorStatistic
+
+        rng = np.random.default_rng(3)
+        items = [("a", (16, 64)), ("b", (8, 64)), ("c", (32, 32))]
+        ws = [torch.from_numpy((rng.standard_normal(s) * 0.05).astype(np.float32)) for _, s in items]
+        stats = [WCTensorStatistic([torch.from_numpy(rng.standard_normal(s[1]).astype(np.float32)) for _ in range(6)],
+                                   [(1, 9, s[1])] * 6) for _, s in items]
+
+        class se_backend:  # noqa: N801
+            @staticmethod
+            def estimate(w, st):
+                sc, zp = O.scale_estimation_params([m.numpy() for m in st.mean_values], st.shape_values, w.numpy(), (1,),
+                                                   "int4_sym", 32, -1, 64, 5, 5)
+                return torch.from_numpy(sc), None
+
+            @staticmethod
+            def pack(w, scale, zp):
+                codes, _, _ = O.do_integer_quantization(w.numpy(), "int4_sym", 32, (1,), scale.numpy(), None)
+                return torch.from_numpy(O.pack_int4(codes)), scale, None
+
+        for sub in (items, items[:1]):
+            got = scale_estimation_sharded(sub, WeightCompressionConfig("int4_sym", 32), lambda i: (ws[i], stats[i]),
+                                           backend=se_backend)
+            ok = ok and sorted(got) == sorted(n for n, _ in sub)
+            for i, (n, _) in enumerate(sub):
+                sc, _ = se_backend.estimate(ws[i], stats[i])
+                ref = se_backend.pack(ws[i], sc, None)
+                ok = ok and torch.equal(got[n][0], ref[0]) and torch.equal(got[n][1], sc) and got[n][2] is None
+        own = run_sharded([1.0, 1.0, 1.0], lambda i: {("k", i): (torch.full((2,), float(i)), None)}, gather=False)
+        ok = ok and 0 < len(own) < 3
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_layer_sharded_gptq_and_scale_estimation():
+    """gptq_sharded / scale_estimation_sharded on two gloo ranks: units go to ranks by LPT on the operation count,
+    each rank loads only its units' activations, nothing but the final payload is exchanged, and every rank ends
+    with the same compressed weights as a single-process run (arithmetic by the oracle: no GPU here)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_data_aware, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=170) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert results == {0: True, 1: True}
