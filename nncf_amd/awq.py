@@ -85,10 +85,13 @@ def data_aware_step(weight: torch.Tensor, reduction_axes, config: WeightCompress
             all_scales[half] = torch.sqrt(gscale)
         if prev_s is not None:
             threshold = FP16_OVERFLOW_MARGIN * FP16_MAX_VALUE
-            mag_base = prev_w[batch_idx, offset:offset + group_size] * prev_s * prev_weight.shape[reduction_axis]
-            magnitudes = mag_base.unsqueeze(0) / all_scales
+            # awq.py:321-335, same operation order: (prev_w / cur_scale) * prev_s * n  vs  prev_w * prev_s * n / threshold
+            gprev = prev_w[batch_idx, offset:offset + group_size]
+            n_prev = prev_weight.shape[reduction_axis]
+            magnitudes = (gprev.unsqueeze(0) / all_scales) * prev_s * n_prev
+            clamped = gprev * prev_s * n_prev / threshold
             clip_rows = magnitudes.amax(dim=1, keepdim=True) >= threshold
-            all_scales = torch.where(clip_rows & ~(magnitudes < threshold), (mag_base / threshold).unsqueeze(0), all_scales)
+            all_scales = torch.where(clip_rows & ~(magnitudes < threshold), clamped.unsqueeze(0), all_scales)
         n_rows, n_tok = gweight.shape[0], gacts.shape[1]
         chunk = max(1, min(steps, (1 << 28) // max(1, n_rows * max(group_size, n_tok))))  # <= 1 GiB of fp32 per temporary
         diffs = []

@@ -542,21 +542,37 @@ def awq_data_free_scale(weight, axis):
     return F32(1) / np.maximum(np.mean(np.abs(weight), axis=axis), EPS)
 
 
+FP16_MAX_VALUE = 65504.0
+FP16_OVERFLOW_MARGIN = 0.25
+
+
 def awq_data_aware_scale(weight, reduction_axis, mode, group_size, mean_values, shape_values, act_ch_axis=-1,
-                         subset_size=32, percent_to_apply=0.002, alpha_min=0.0, alpha_max=1.0, steps=100):
-    """awq.py:243-357 without the prev-matmul (merge) clamp branch. 2-D weights."""
+                         subset_size=32, percent_to_apply=0.002, alpha_min=0.0, alpha_max=1.0, steps=100,
+                         prev_weight=None, prev_mean_values=None, prev_shape_values=None):
+    """awq.py:243-357, 2-D and 3-D (MoE) weights, incl. the clamp of the scale when the previous matmul's output
+    (it absorbs 1/scale) would leave the fp16 range (awq.py:315-335, _clamp_scale :360-361)."""
     alpha_step = (alpha_max - alpha_min) / steps
     s, X = process_stats(mean_values, shape_values, subset_size, act_ch_axis)
-    s = _f32(s)[None]
-    X = _f32(X)[None]
-    weight = _f32(weight)[None]
-    reduction_axis += 1
+    s = _f32(s)
+    X = _f32(X)
+    weight = _f32(weight)
+    is_2d = weight.ndim == 2
+    if is_2d:
+        s, X, weight = s[None], X[None], weight[None]
+        prev_weight = _f32(prev_weight)[None] if prev_weight is not None else None
+        reduction_axis += 1
+    prev_s = prev_w = None
+    if prev_mean_values is not None and prev_weight is not None:
+        ps, _ = process_stats(prev_mean_values, prev_shape_values, subset_size, act_ch_axis)
+        prev_s = float(np.max(_f32(ps)))
+        prev_w = np.mean(np.abs(_f32(prev_weight)), axis=reduction_axis)
     top_k = max(int(s.shape[-1] * percent_to_apply), 1)
     topk = np.argsort(-s, kind="stable")[:, :top_k]
     gs = group_size if group_size != -1 else s.shape[-1]
     groups = sorted({(b, int(topk[b, k]) // gs) for b in range(topk.shape[0]) for k in range(topk.shape[1])})
     if reduction_axis == 1:
         weight = np.moveaxis(weight, -1, -2)
+        reduction_axis = weight.ndim - 1
     scale = np.ones_like(np.mean(X, axis=-1))
     for b, gi in groups:
         off = gi * gs
@@ -571,6 +587,13 @@ def awq_data_aware_scale(weight, reduction_axis, mode, group_size, mean_values, 
         alpha = alpha_min
         for _ in range(steps):
             cur = (gscale ** F32(alpha)).astype(np.float32)
+            if prev_s is not None:
+                threshold = FP16_OVERFLOW_MARGIN * FP16_MAX_VALUE
+                n_prev = prev_weight.shape[reduction_axis]
+                magnitudes = (prev_w[b, off:off + gs] / cur) * F32(prev_s) * F32(n_prev)
+                if magnitudes.max() >= threshold:
+                    clamped = prev_w[b, off:off + gs] * F32(prev_s) * F32(n_prev) / F32(threshold)
+                    cur = np.where(magnitudes < threshold, cur, clamped).astype(np.float32)
             wq = gweight * cur
             dq = _qdq(wq, mode, -1, -1)
             sacts = gacts / cur[:, None]
@@ -582,7 +605,7 @@ def awq_data_aware_scale(weight, reduction_axis, mode, group_size, mean_values, 
             alpha += alpha_step
         if best is not None:
             scale[b, off:off + gs] = best
-    return scale[0]
+    return scale[0] if is_2d else scale
 
 
 # ------------------------------------------------------------------ GPTQ

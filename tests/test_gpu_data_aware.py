@@ -318,6 +318,94 @@ def test_fused_se_search_equals_stepwise_path(mode, gs, penalty):
         assert torch.equal(a_z, b_z)
 
 
+def _stat_from(means, shapes):
+    from nncf_amd.statistics import WCTensorStatistic
+    return WCTensorStatistic([torch.from_numpy(np.ascontiguousarray(m)).cuda() for m in means],
+                             [tuple(int(v) for v in s) for s in shapes])
+
+
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym"])
+def test_golden_awq_clamp_branch(golden, mode):
+    """AWQ data-aware step with the previous matmul merged: the fp16-overflow clamp (awq.py:315-335, _clamp_scale
+    :360) against what the reference returned (tools/gen_golden_extra.py)."""
+    from nncf_amd import awq
+    g = golden("se_awq_extra")
+    sc = awq.data_aware_step(to_dev(g["clamp_w"], "f32"), (1,), _cfg(mode, 32), _stat_from(g["clamp_means"], g["clamp_shapes"]),
+                             -1, 8, 0.02, 0.0, 1.0, 20, prev_weight=to_dev(g["clamp_prev_w"], "f32"),
+                             prev_statistics=_stat_from(g["clamp_prev_means"], g["clamp_prev_shapes"]))
+    np.testing.assert_allclose(host(sc), g[f"clamp_awq_{mode}_scale"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym"])
+def test_golden_awq_3d_weights(golden, mode):
+    """MoE weight [experts, hidden, out] reduced along axis 1 (awq.py:255-289)."""
+    from nncf_amd import awq
+    g = golden("se_awq_extra")
+    w_ekn = np.ascontiguousarray(np.moveaxis(g["moe_w_enk"], -1, -2))
+    sc = awq.data_aware_step(to_dev(w_ekn, "f32"), (1,), _cfg(mode, 32), _stat_from(g["moe_means"], g["moe_shapes"]),
+                             -1, 8, 0.05, 0.0, 1.0, 20)
+    assert tuple(sc.shape) == g[f"moe_awq_{mode}_scale"].shape
+    np.testing.assert_allclose(host(sc), g[f"moe_awq_{mode}_scale"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("axis", [2, 1])
+@pytest.mark.parametrize("gs", [32, -1])
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym", "nf4"])
+def test_golden_scale_estimation_3d_weights(golden, mode, gs, axis):
+    """MoE weights through scale estimation, reduction along the last axis ([E, N, K]) and along axis 1 ([E, K, N],
+    the transposed branch, scale_estimation.py:206-212) against the reference's outputs."""
+    from nncf_amd import scale_estimation as SE
+    g = golden("se_awq_extra")
+    w = g["moe_w_enk"] if axis == 2 else np.ascontiguousarray(np.moveaxis(g["moe_w_enk"], -1, -2))
+    s, z = SE.calculate_quantization_params(_stat_from(g["moe_means"], g["moe_shapes"]), to_dev(w, "f32"), (axis,),
+                                            _cfg(mode, gs), -1, 8, 3, 4)
+    key = f"moe_se_{mode}_g{gs}_ax{axis}"
+    assert tuple(s.shape) == g[key + "_scale"].shape
+    np.testing.assert_allclose(host(s), g[key + "_scale"], rtol=1e-5, atol=1e-9)
+    if z is not None:
+        assert np.array_equal(host(z), g[key + "_zp"])
+
+
+from tests.se_literals import se_literal_inputs, se_literal_params  # noqa: E402
+
+
+@pytest.mark.parametrize("mode,init,steps,transpose_a,n_samples,ref_scale,ref_zp", se_literal_params())
+def test_scale_estimation_reference_literals(mode, init, steps, transpose_a, n_samples, ref_scale, ref_zp):
+    """The literal scales / zero points of the reference's own template test
+    (tests/cross_fw/test_templates/template_test_weights_compression.py:409-623), its tolerance (atol 1e-3)."""
+    from nncf_amd import scale_estimation as SE
+    from nncf_amd.statistics import activations_to_wc_statistics
+    w, acts = se_literal_inputs(n_samples)
+    stats = activations_to_wc_statistics([torch.from_numpy(a).cuda() for a in acts])
+    axes, ch = ((0,), 1) if transpose_a else ((1,), 2)
+    sc, zp = SE.calculate_quantization_params(stats, torch.from_numpy(w).cuda(), axes, _cfg(mode, 8), ch, 2, init, steps)
+    assert sc.dtype == torch.float32
+    np.testing.assert_allclose(host(sc), np.array(ref_scale, np.float32).reshape(tuple(sc.shape)), atol=1e-3, rtol=0)
+    if ref_zp is None:
+        assert zp is None
+    else:
+        np.testing.assert_allclose(host(zp), np.array(ref_zp, np.float32).reshape(tuple(zp.shape)), atol=1e-3, rtol=0)
+
+
+def test_gptq_against_the_independent_autogptq_reference(golden):
+    """HIP Hessian (2-D per expert and the 3-D / MoE form) + gptq.quantize_weights against the AutoGPTQ-derived torch
+    reference the reference's own GPTQ test compares with (tests/openvino/native/quantization/test_gptq.py:168-325,
+    :355-452): INT4_SYM, group 16, damp 0.1, seeded inputs of that test.  Its bar is np.isclose on everything; after
+    the Cholesky chain single entries may flip under last-bit differences, so the weights take >= 99 %."""
+    from nncf_amd import gptq
+    from tests.test_oracle_golden import autogptq_inputs
+    g = golden("gptq_autogptq")
+    inputs, weights = autogptq_inputs()
+    H3 = gptq.calculate_hessian([torch.from_numpy(x).cuda() for x in inputs], is_3d_weight=True)
+    for e in range(4):
+        H = gptq.calculate_hessian([torch.from_numpy(x[e][None]).cuda() for x in inputs])[0]
+        assert np.all(np.isclose(g[f"H_{e}"], host(H), rtol=1e-5, atol=1e-5))
+        assert np.all(np.isclose(g[f"H_{e}"], host(H3[e]), rtol=1e-5, atol=1e-5))
+        q, s, _ = gptq.quantize_weights(H.clone(), torch.from_numpy(weights[e].copy()).cuda(), _cfg("int4_sym", 16))
+        assert np.all(np.isclose(g[f"scale_{e}"].reshape(tuple(s.shape)), host(s)))
+        assert np.isclose(g[f"weight_{e}"], host(q)).mean() >= 0.99
+
+
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 63, 64, 65, 100, 127, 128])
 def test_cholinv_block_kernel(n):
     """nncf_amd_cholinv_block (one workgroup, n <= 128) vs fp64 cholesky + triangular inverse: the block is a

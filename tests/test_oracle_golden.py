@@ -159,3 +159,65 @@ def test_gptq_quantize(golden, mode, gs, se):
     np.testing.assert_allclose(s, g[key + "_scale"], rtol=1e-3, atol=1e-6)
     if z is not None:
         assert (z == g[key + "_zp"]).mean() > 0.98
+
+
+# ------------------------------------------------------------------ round-2 fixtures (tools/gen_golden_extra.py)
+def _shapes(a):
+    return [tuple(int(v) for v in r) for r in a]
+
+
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym"])
+def test_awq_clamp_branch(golden, mode):
+    """AWQ with the previous matmul merged: the fp16-overflow clamp of awq.py:315-335 is taken (80 times while the
+    fixture was generated)."""
+    g = golden("se_awq_extra")
+    assert int(g["clamp_calls"]) > 0
+    sc = O.awq_data_aware_scale(g["clamp_w"], 1, mode, 32, list(g["clamp_means"]), _shapes(g["clamp_shapes"]), -1, 8, 0.02,
+                                0.0, 1.0, 20, g["clamp_prev_w"], list(g["clamp_prev_means"]), _shapes(g["clamp_prev_shapes"]))
+    np.testing.assert_allclose(sc, g[f"clamp_awq_{mode}_scale"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym"])
+def test_awq_3d_weights(golden, mode):
+    g = golden("se_awq_extra")
+    w_ekn = np.ascontiguousarray(np.moveaxis(g["moe_w_enk"], -1, -2))
+    sc = O.awq_data_aware_scale(w_ekn, 1, mode, 32, list(g["moe_means"]), _shapes(g["moe_shapes"]), -1, 8, 0.05, 0.0, 1.0, 20)
+    assert sc.shape == g[f"moe_awq_{mode}_scale"].shape
+    np.testing.assert_allclose(sc, g[f"moe_awq_{mode}_scale"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("axis", [2, 1])
+@pytest.mark.parametrize("gs", [32, -1])
+@pytest.mark.parametrize("mode", ["int4_sym", "int4_asym", "nf4"])
+def test_scale_estimation_3d_weights(golden, mode, gs, axis):
+    g = golden("se_awq_extra")
+    w = g["moe_w_enk"] if axis == 2 else np.ascontiguousarray(np.moveaxis(g["moe_w_enk"], -1, -2))
+    s, z = O.scale_estimation_params(list(g["moe_means"]), _shapes(g["moe_shapes"]), w, (axis,), mode, gs, -1, 8, 3, 4)
+    key = f"moe_se_{mode}_g{gs}_ax{axis}"
+    assert s.shape == g[key + "_scale"].shape
+    np.testing.assert_allclose(s, g[key + "_scale"], rtol=1e-6)
+    if z is not None:
+        assert np.array_equal(z, g[key + "_zp"])
+
+
+def autogptq_inputs():
+    """The seeded inputs of the reference's own GPTQ test (tests/openvino/native/quantization/test_gptq.py:355-371)."""
+    np.random.seed(0)
+    inputs = [np.random.rand(4, 128, 32).astype(np.float32) for _ in range(10)]
+    weights = np.random.rand(4, 20, 32).astype(np.float32)
+    return inputs, weights
+
+
+@pytest.mark.parametrize("expert", [0, 1, 2, 3])
+def test_gptq_against_the_independent_autogptq_reference(golden, expert):
+    """The oracle's GPTQ (Hessian + column loop) against the outputs of the AutoGPTQ-derived torch implementation the
+    reference's own test compares with (test_gptq.py:168-325), INT4_SYM, group 16, damp 0.1, same bar as that test
+    (np.isclose on the Hessian, the scales and the quantized weights, :421-452)."""
+    g = golden("gptq_autogptq")
+    inputs, weights = autogptq_inputs()
+    assert np.array_equal(inputs[0][0, 0], g["check_first_input_row"]) and np.array_equal(weights[0, 0], g["check_weight_row"])
+    H = O.gptq_hessian([x[expert][None] for x in inputs])[0]
+    assert np.all(np.isclose(g[f"H_{expert}"], H))
+    q, s, _ = O.gptq_quantize_weights(H.copy(), weights[expert].copy(), "int4_sym", 16)
+    assert np.all(np.isclose(g[f"scale_{expert}"].reshape(s.shape), s))
+    assert np.all(np.isclose(g[f"weight_{expert}"], q))

@@ -160,3 +160,23 @@ def test_nf4_centers_stay_clear_of_bucket_boundaries():
     assert np.min(np.abs(c - np.round(c))) > 0.02
     buckets = np.floor(c).astype(int)
     assert len(set(buckets.tolist())) == len(buckets)  # at most one center per bucket
+
+
+# ---- scale estimation literals of the reference's template test
+from tests.se_literals import se_literal_inputs, se_literal_params  # noqa: E402
+
+
+@pytest.mark.parametrize("mode,init,steps,transpose_a,n_samples,ref_scale,ref_zp", se_literal_params())
+def test_scale_estimation_literals(mode, init, steps, transpose_a, n_samples, ref_scale, ref_zp):
+    """template_test_weights_compression.py:566-623: transpose_a -> reduction axis 0 / act_ch_axis 1, else 1 / 2;
+    subset_size 2, group size 8, atol 1e-3."""
+    w, acts = se_literal_inputs(n_samples)
+    means, shapes = O.activations_to_wc_statistics(acts)
+    axes, ch = ((0,), 1) if transpose_a else ((1,), 2)
+    sc, zp = O.scale_estimation_params(means, shapes, w, axes, mode, 8, ch, 2, init, steps)
+    np.testing.assert_allclose(sc, np.array(ref_scale, np.float32).reshape(sc.shape), atol=1e-3, rtol=0)
+    assert sc.dtype == np.float32
+    if ref_zp is None:
+        assert zp is None
+    else:
+        np.testing.assert_allclose(zp, np.array(ref_zp, np.float32).reshape(zp.shape), atol=1e-3, rtol=0)
