@@ -130,6 +130,17 @@ int nncf_amd_int_quant_error(const void* weight, int w_dtype, int64_t outer, int
                              size_t workspace_bytes, void* stream);
 
 /*
+ * The metric of MANY 2-D [rows, cols] weights (reduced along the columns) in two launches per 48 tensors: the scoring
+ * loop of the mixed-precision criteria (src/nncf/quantization/algorithms/weight_compression/mixed_precision.py:161-199,
+ * :350-361 call get_integer_quantization_error weight by weight).  weights_host / rows_host / cols_host: HOST arrays
+ * of n entries; results: fp32 [n] on the device; workspace: nncf_amd_int_quant_error_batched_workspace bytes.
+ */
+size_t nncf_amd_int_quant_error_batched_workspace(int n, const int64_t* rows_host);
+int nncf_amd_int_quant_error_batched(int n, const void* const* weights_host, int w_dtype, const int64_t* rows_host,
+                                     const int64_t* cols_host, int64_t group_size, int mode, int reduction,
+                                     float* results, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * The same metric WITHOUT any caller workspace and without any allocation.  No counterpart in the reference: it is
  * for callers that cannot allocate device memory around the call (HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  The per-channel partial sums live in a 1 MiB device array inside the library (one copy per

@@ -34,6 +34,9 @@ SIGNATURES = {
     "nncf_amd_int_quant_error_workspace": (c_size_t, [c_int64, c_int64]),
     "nncf_amd_int_quant_error": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nncf_amd_int_quant_error_batched_workspace": (c_size_t, [c_int, POINTER(c_int64)]),
+    "nncf_amd_int_quant_error_batched": (c_int, [c_int, POINTER(c_void_p), c_int, POINTER(c_int64), POINTER(c_int64),
+                                                 c_int64, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nncf_amd_int_quant_error_static": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                                                 c_void_p, c_void_p]),
     "nncf_amd_pack_u4": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

@@ -227,6 +227,68 @@ __global__ __launch_bounds__(256) void k_err_final(const float* ws, int64_t chan
     if (threadIdx.x == 0) out[0] = reduction == NNCF_AMD_ERR_MAX_MEAN ? mx / (float)r : sqrtf(sum);
 }
 
+// ------------------------------------------------------------------ error metric of MANY weights in two launches
+// (the mixed-precision scoring loop, mixed_precision.py:161-199, walks the weights one by one).  2-D [rows, cols]
+// weights reduced along the columns.  Pass 1: one block per row of any tensor -> ws[global row]; pass 2: one block per
+// tensor -> results[i].
+constexpr int kErrBatch = 48;
+struct ErrBatchArgs {
+    int n, mode, reduction;
+    int64_t gs;                         // -1: the whole row
+    uint32_t row_start[kErrBatch + 1];  // prefix sums of the row counts
+    uint32_t cols[kErrBatch];
+    const void* w[kErrBatch];
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_err_rows_batch(ErrBatchArgs a, float* ws) {
+    __shared__ float smem[8];
+    const IntMode m = int_mode(a.mode);
+    const uint32_t grow = blockIdx.x;
+    int i = 0;
+    while (grow >= a.row_start[i + 1]) ++i;  // block-uniform
+    const int64_t r = a.cols[i];
+    const int64_t gs = a.gs == -1 ? r : a.gs;
+    const int64_t base = (int64_t)(grow - a.row_start[i]) * r;
+    const void* w = a.w[i];
+    float acc = 0.0f;
+    for (int64_t g0 = 0; g0 < r; g0 += gs) {
+        float lo = __builtin_inff(), hi = -__builtin_inff();
+        for (int64_t k = threadIdx.x; k < gs; k += 256) {
+            const float f = Elem<DT>::load(w, base + g0 + k);
+            lo = fminf(lo, f);
+            hi = fmaxf(hi, f);
+        }
+        lo = block_allreduce<4>(lo, OpMin(), smem);
+        hi = block_allreduce<4>(hi, OpMax(), smem + 4);
+        float scale, zpf;
+        int zpi;
+        int_params(lo, hi, m, scale, zpf, zpi);
+        for (int64_t k = threadIdx.x; k < gs; k += 256) {
+            const float f = Elem<DT>::load(w, base + g0 + k);
+            const float q = int_quant(f, scale, zpf, m.asym, m);
+            const float dq = m.asym ? (q - zpf) * scale : q * scale;
+            const float d = dq - f;
+            acc += d * d;
+        }
+    }
+    acc = block_allreduce<4>(acc, OpAdd(), smem);
+    if (threadIdx.x == 0) ws[grow] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_err_final_batch(ErrBatchArgs a, const float* ws, float* out) {
+    __shared__ float smem[8];
+    const int i = blockIdx.x;
+    float mx = 0.0f, sum = 0.0f;
+    for (uint32_t c = a.row_start[i] + threadIdx.x; c < a.row_start[i + 1]; c += 256) {
+        mx = fmaxf(mx, ws[c]);
+        sum += ws[c];
+    }
+    mx = block_allreduce<4>(mx, OpMax(), smem);
+    sum = block_allreduce<4>(sum, OpAdd(), smem + 4);
+    if (threadIdx.x == 0) out[i] = a.reduction == NNCF_AMD_ERR_MAX_MEAN ? mx / (float)a.cols[i] : sqrtf(sum);
+}
+
 }  // namespace wc
 
 using namespace wc;
@@ -404,4 +466,85 @@ extern "C" int nncf_amd_int_quant_error(const void* weight, int w_dtype, int64_t
     if (st != NNCF_AMD_OK) return st;
     hipLaunchKernelGGL(k_err_final, dim3(1), dim3(256), 0, s, (const float*)ws, channels, r, reduction, result);
     return launch_status("err_final");
+}
+
+extern "C" size_t nncf_amd_int_quant_error_batched_workspace(int n, const int64_t* rows_host) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += rows_host && rows_host[i] > 0 ? (size_t)rows_host[i] : 0;
+    return total * sizeof(float);
+}
+
+extern "C" int nncf_amd_int_quant_error_batched(int n, const void* const* weights_host, int w_dtype,
+                                                const int64_t* rows_host, const int64_t* cols_host, int64_t group_size,
+                                                int mode, int reduction, float* results, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+    if (mode < NNCF_AMD_INT8_ASYM || mode > NNCF_AMD_INT4_SYM) {
+        set_error("int_quant_error_batched: mode %d is not an integer mode", mode);
+        return NNCF_AMD_ERR_MODE;
+    }
+    if (reduction != NNCF_AMD_ERR_MAX_MEAN && reduction != NNCF_AMD_ERR_FROBENIUS) {
+        set_error("Unsupported aggregation mode: %d.", reduction);
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (n < 0 || (n > 0 && (!weights_host || !rows_host || !cols_host || !results)) || (group_size < 1 && group_size != -1)) {
+        set_error("int_quant_error_batched: bad argument");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (w_dtype != NNCF_AMD_F32 && w_dtype != NNCF_AMD_F16 && w_dtype != NNCF_AMD_BF16) {
+        set_error("int_quant_error_batched: unsupported weight dtype %d", w_dtype);
+        return NNCF_AMD_ERR_DTYPE;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!weights_host[i] || rows_host[i] < 1 || cols_host[i] < 1 || cols_host[i] > 0x7fffffff) {
+            set_error("int_quant_error_batched: tensor %d: NULL or empty", i);
+            return NNCF_AMD_ERR_BAD_ARG;
+        }
+        if (group_size != -1 && cols_host[i] % group_size) {
+            set_error("Channel size %lld should be divisible by size of group %lld.", (long long)cols_host[i],
+                      (long long)group_size);
+            return NNCF_AMD_ERR_GROUP_SIZE;
+        }
+    }
+    if (workspace_bytes < nncf_amd_int_quant_error_batched_workspace(n, rows_host) || (n > 0 && !workspace)) {
+        set_error("int_quant_error_batched: workspace needs %lld bytes",
+                  (long long)nncf_amd_int_quant_error_batched_workspace(n, rows_host));
+        return NNCF_AMD_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    for (int first = 0; first < n;) {
+        ErrBatchArgs a = {};
+        a.mode = mode;
+        a.reduction = reduction;
+        a.gs = group_size;
+        uint64_t acc = 0;
+        int j = 0;
+        for (; j < kErrBatch && first + j < n; ++j) {
+            if (acc + (uint64_t)rows_host[first + j] > 0x7fffffffull) break;  // 32-bit row ids / grid
+            a.row_start[j] = (uint32_t)acc;
+            a.cols[j] = (uint32_t)cols_host[first + j];
+            a.w[j] = weights_host[first + j];
+            acc += (uint64_t)rows_host[first + j];
+        }
+        if (j == 0) {
+            set_error("int_quant_error_batched: tensor %d has too many rows", first);
+            return NNCF_AMD_ERR_UNSUPPORTED;
+        }
+        a.row_start[j] = (uint32_t)acc;
+        a.n = j;
+        const dim3 grid((unsigned)acc);
+        switch (w_dtype) {
+            case NNCF_AMD_F32: hipLaunchKernelGGL((k_err_rows_batch<NNCF_AMD_F32>), grid, dim3(256), 0, s, a, ws); break;
+            case NNCF_AMD_F16: hipLaunchKernelGGL((k_err_rows_batch<NNCF_AMD_F16>), grid, dim3(256), 0, s, a, ws); break;
+            default: hipLaunchKernelGGL((k_err_rows_batch<NNCF_AMD_BF16>), grid, dim3(256), 0, s, a, ws); break;
+        }
+        int st = launch_status("err_rows_batch");
+        if (st != NNCF_AMD_OK) return st;
+        hipLaunchKernelGGL(k_err_final_batch, dim3((unsigned)j), dim3(256), 0, s, a, (const float*)ws, results + first);
+        st = launch_status("err_final_batch");
+        if (st != NNCF_AMD_OK) return st;
+        ws += acc;
+        first += j;
+    }
+    return NNCF_AMD_OK;
 }

@@ -271,12 +271,43 @@ def get_integer_quantization_errors(weights, reduction_axes_list, config: Weight
                                     reduction: str):
     """The error metric of MANY weights (the mixed-precision scoring loop, mixed_precision.py:189-199) with every
     launch queued back to back and ONE device synchronisation at the end, instead of one `.item()` per weight."""
+    import ctypes
+
     weights = list(weights)
     if not weights:
         return []
+    if reduction not in ["max_mean", "frobenius"]:
+        exception_str = f"Unsupported aggregation mode: {reduction}."
+        raise InternalError(exception_str)
+    config = as_config(config)
+    axes_list = list(reduction_axes_list)
+    # 2-D weights of one dtype reduced along their last axis (every nn.Linear): ONE pair of launches per 48 weights
+    # (nncf_amd_int_quant_error_batched) instead of a pair per weight
+    plain = all(isinstance(w, torch.Tensor) and w.is_cuda and w.ndim == 2 and w.numel() > 0 and w.dtype == weights[0].dtype
+                and w.device == weights[0].device and _single_axis(2, ax) == 1 for w, ax in zip(weights, axes_list))
+    if plain:
+        ws_list = [_prep_weight(w, "get_integer_quantization_errors") for w in weights]
+        n, dev = len(ws_list), ws_list[0].device
+        for w in ws_list:
+            if config.group_size != -1 and w.shape[1] % config.group_size != 0:
+                msg = f"Channel size {w.shape[1]} should be divisible by size of group {config.group_size}."
+                raise InvalidGroupSizeError(msg)
+        L = _lib.lib()
+        c_w = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws_list])
+        c_rows = (ctypes.c_int64 * n)(*[w.shape[0] for w in ws_list])
+        c_cols = (ctypes.c_int64 * n)(*[w.shape[1] for w in ws_list])
+        nbytes = L.nncf_amd_int_quant_error_batched_workspace(n, c_rows)
+        work = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+        res = torch.empty(n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.nncf_amd_int_quant_error_batched(n, c_w, _lib.dtype_id(ws_list[0]), c_rows, c_cols,
+                                                          config.group_size, _lib.MODE_ID[config.mode.value],
+                                                          0 if reduction == "max_mean" else 1, _lib.ptr(res),
+                                                          _lib.ptr(work), nbytes, _lib.stream_of(ws_list[0])))
+        return res.tolist()
     res = torch.empty(len(weights), dtype=torch.float32, device=weights[0].device)
     keep = [_queue_quantization_error(w, axes, config, reduction, res[i:i + 1])
-            for i, (w, axes) in enumerate(zip(weights, reduction_axes_list))]
+            for i, (w, axes) in enumerate(zip(weights, axes_list))]
     out = res.tolist()
     del keep
     return out
