@@ -15,6 +15,7 @@ import os
 
 import torch
 
+from nncf_amd import errors as _errors
 from nncf_amd import gptq as _gptq
 from nncf_amd import statistics as _stats
 from nncf_amd import weight_lowering as _wl
@@ -135,23 +136,27 @@ def install():
     patch(QF, "pack_uint4", mk_pack(_wl.pack_uint4))
     patch(QF, "pack_int4", mk_pack(_wl.pack_int4))
 
-    def mk_reducer(cls_amd):
+    def mk_reducer(cls_amd, needs_keepdims):
         def make(orig):
             def f(self, x):
                 t = _raw(x[0])
-                if isinstance(t, torch.Tensor) and t.is_cuda and os.environ.get("NNCF_AMD_DISABLE") is None:
+                if (isinstance(t, torch.Tensor) and t.is_cuda and os.environ.get("NNCF_AMD_DISABLE") is None
+                        and (not needs_keepdims or getattr(self, "_keepdims", True))):
+                    # the reference resolves its axes through the reducer's axes mode (collectors.py:494-538)
+                    axes = C.determine_reduction_axes(t.ndim, self._axes, self._axes_mode)
                     try:
-                        return [Tensor(cls_amd(self._axes)._reduce_out_of_place([t])[0])]
-                    except Exception:  # axes outside the weight-compression statistic forms: reference path
-                        pass
+                        return [Tensor(cls_amd(tuple(axes))._reduce_out_of_place([t])[0])]
+                    except _errors.UnsupportedModelError:
+                        pass  # axes outside the weight-compression statistic forms: reference path
+                    # anything else (launch failures, bad status) is an error of this library and propagates
                 return orig(self, x)
             return f
         return make
 
-    patch(C.MeanReducer, "_reduce_out_of_place", mk_reducer(_stats.MeanReducer))
-    patch(C.MeanVarianceReducer, "_reduce_out_of_place", mk_reducer(_stats.MeanVarianceReducer))
-    patch(C.MaxVarianceReducer, "_reduce_out_of_place", mk_reducer(_stats.MaxVarianceReducer))
-    patch(C.MeanAbsMaxReducer, "_reduce_out_of_place", mk_reducer(_stats.MeanAbsMaxReducer))
+    patch(C.MeanReducer, "_reduce_out_of_place", mk_reducer(_stats.MeanReducer, True))
+    patch(C.MeanVarianceReducer, "_reduce_out_of_place", mk_reducer(_stats.MeanVarianceReducer, False))
+    patch(C.MaxVarianceReducer, "_reduce_out_of_place", mk_reducer(_stats.MaxVarianceReducer, False))
+    patch(C.MeanAbsMaxReducer, "_reduce_out_of_place", mk_reducer(_stats.MeanAbsMaxReducer, False))
 
     def mk_hessian(orig):
         def f(self, node, inputs, is_3d_weight=False):

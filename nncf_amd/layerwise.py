@@ -116,9 +116,17 @@ class LayerwiseFeeder:
         order = {n: i for i, n in enumerate(trace.order)}
         targets = sorted((n for n in target_names if n in trace.act_key), key=lambda n: order[n])
         # groups of Linears reading the same activation, in execution order of their first member
-        groups: Dict[int, List[str]] = {}
+        # (the trace's activation key predates AWQ: members whose inputs AWQ rescales differently, or only some of
+        # them, do NOT see the same tensor any more -- the Hessian is taken behind the member's own input multiply, so
+        # such members get groups of their own; the reference builds one Hessian per node, gptq.py:118-140)
+        def input_scale_key(name):
+            sq = getattr(mods[name], "awq_input_scale", None)
+            val = getattr(sq, "_scale_value", None)
+            return None if val is None else hash(val.detach().float().cpu().numpy().tobytes())
+
+        groups: Dict[tuple, List[str]] = {}
         for n in targets:
-            groups.setdefault(trace.act_key[n], []).append(n)
+            groups.setdefault((trace.act_key[n], input_scale_key(n)), []).append(n)
         self._groups = sorted(groups.values(), key=lambda g: order[g[0]])
         self._mods = mods
         # decoder blocks: children of ModuleLists that hold targets
@@ -228,6 +236,11 @@ class LayerwiseFeeder:
                     mean, _ = activation_stats(x2.reshape(1, -1, k), want_stats=False)
                     stats.mean_values.append(mean.to(x.dtype))
                     stats.shape_values.append(tuple(x.shape))
+                if not stats.mean_values:
+                    # no calibration forward reached these Linears: an all-zero Hessian would mark every column
+                    # dead and GPTQ would zero the whole weight
+                    msg = f"GPTQ: no calibration sample reached {group}; exclude them (ignored_scope) or fix the dataset"
+                    raise RuntimeError(msg)
                 yield group, acc.result(), stats
         finally:
             for w in workers:  # the rest of the model is not needed (or the consumer stopped early)
@@ -265,6 +278,9 @@ class LayerwiseFeeder:
                     raise _EarlyExit
 
                 self._run(first, pre_hook=pre)
+                if not stats.mean_values:
+                    msg = f"GPTQ: no calibration sample reached {group}; exclude them (ignored_scope) or fix the dataset"
+                    raise RuntimeError(msg)
                 yield group, acc.result(), stats
                 # the caller has replaced the weights of `group` by now; close the block if this was its last group
                 blk = self._block_of.get(group[0])

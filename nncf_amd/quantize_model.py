@@ -856,6 +856,15 @@ def load_statistics(path: str, device, tag: str):
 _DTYPES = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16, "float64": torch.float64}
 
 
+def _decompressor_classes():
+    return {n: c for n, c in vars(dcmp).items()
+            if isinstance(c, type) and issubclass(c, dcmp.BaseWeightsDecompressor) and c is not dcmp.BaseWeightsDecompressor
+            and not n.startswith("_")}
+
+
+_DECOMPRESSORS = _decompressor_classes()
+
+
 def save_compressed(model: nn.Module, path: str) -> None:
     """Writes the compressed model as ONE safetensors file: the model's state_dict (packed weights, fp16 / E8M0
     scales, packed zero points, AWQ activation scales, everything left uncompressed) plus a JSON header that says
@@ -880,14 +889,16 @@ def save_compressed(model: nn.Module, path: str) -> None:
                 e["shares_weight_with"] = first
             entries[name] = e
     sq = [name for name, mod in model.named_modules() if isinstance(getattr(mod, "awq_input_scale", None), SQMultiply)]
-    tensors, seen = {}, {}
+    tensors, seen, aliases = {}, {}, {}
     for k, v in model.state_dict().items():
-        key = (v.data_ptr(), tuple(v.shape), v.dtype)
+        key = (v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.storage_offset(), v.dtype)
         if v.numel() and key in seen:  # tied tensors are stored once (safetensors refuses shared storage)
+            aliases[k] = seen[key]
             continue
         seen[key] = k
         tensors[k] = v.detach().contiguous()
-    save_file(tensors, path, metadata={"nncf_amd_weight_compression": json.dumps({"weights": entries, "awq": sq})})
+    save_file(tensors, path, metadata={"nncf_amd_weight_compression": json.dumps(
+        {"weights": entries, "awq": sq, "aliases": aliases})})
 
 
 def load_compressed(model: nn.Module, path: str) -> nn.Module:
@@ -910,7 +921,9 @@ def load_compressed(model: nn.Module, path: str) -> nn.Module:
             packed, dec = made[src]
         else:
             prefix = f"{name}.parametrizations.weight."
-            cls = getattr(dcmp, e["decompressor"])
+            cls = _DECOMPRESSORS.get(e["decompressor"])
+            if cls is None:  # the header is data from a file: only the decompressor classes may be named
+                raise InternalError(f"load_compressed: unknown decompressor {e['decompressor']!r} for {name}")
             dec = cls.__new__(cls)
             nn.Module.__init__(dec)
             dec.register_buffer("_scale", tensors[prefix + "0._scale"])
@@ -929,5 +942,13 @@ def load_compressed(model: nn.Module, path: str) -> nn.Module:
     missing, unexpected = model.load_state_dict(tensors, strict=False)
     if unexpected:
         raise InternalError(f"load_compressed: tensors without a place in the model: {unexpected[:5]}")
+    # keys the file does not hold must be the tied / shared ones it recorded (stored once); anything else means a
+    # truncated or mismatched file and would leave parameters at their initial values
+    aliases = header.get("aliases", {})
+    shared = {f"{n}.parametrizations.weight.{k}" for n, e in header["weights"].items() if e.get("shares_weight_with")
+              for k in ("original", "0._scale", "0._zero_point")}
+    lost = [k for k in missing if k not in aliases and k not in shared]
+    if lost:
+        raise InternalError(f"load_compressed: the file has no tensor for {lost[:5]} ({len(lost)} keys)")
     model.requires_grad_(False)
     return model
