@@ -227,6 +227,16 @@ int nncf_amd_hessian_accumulate_upper(float* h, const void* x, int x_dtype, int6
 int nncf_amd_hessian_finalize(float* h, int64_t k, float scale, void* stream);
 
 /*
+ * The `_upper` accumulation (beta = 1) over a LIST of separately allocated calibration items x_i [tokens_i, k], as
+ * GPTQ._calculate_hessian receives them (gptq.py:225-240 loops over `inputs`): one launch per 128 items instead of a
+ * concatenation copy + launch (16-bit items, 2048 <= k, k % 8 == 0, 16-byte aligned: the 256x256-tile MFMA kernel walks
+ * the list, items are zero-padded to 32-token stages by the buffer bounds check; other shapes run item by item).
+ * xs_host / tokens_host are HOST arrays of n entries.  Finish with nncf_amd_hessian_finalize.
+ */
+int nncf_amd_hessian_accumulate_list(float* h, int n, const void* const* xs_host, const int64_t* tokens_host,
+                                     int x_dtype, int64_t k, float alpha, void* stream);
+
+/*
  * Fused inner step of scale estimation (ScaleEstimation.calculate_quantization_params,
  * src/nncf/quantization/algorithms/weight_compression/scale_estimation.py:300-360; get_target_zero_mask :380-393,
  * estimate_scales :396-409): quantize every group with the candidate `scale` (and `zero_point`, fp32 as scale

@@ -66,6 +66,8 @@ SIGNATURES = {
     "nncf_amd_hessian_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_float, c_float, c_void_p]),
     "nncf_amd_hessian_accumulate_upper": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_float, c_float,
                                                   c_void_p]),
+    "nncf_amd_hessian_accumulate_list": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64), c_int, c_int64,
+                                                 c_float, c_void_p]),
     "nncf_amd_hessian_finalize": (c_int, [c_void_p, c_int64, c_float, c_void_p]),
     "nncf_amd_gptq_block": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),

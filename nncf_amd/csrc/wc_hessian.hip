@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_syrk16(float* __restrict__ h, const voi
 // writes LDS linearly, hence the permutation is applied to its global source addresses.
 constexpr int GB = 256;     // tile edge
 constexpr int GK = 32;      // tokens per stage
-constexpr int GST = 4;      // stages (LDS buffers)
+constexpr int GST = 4;      // stages (LDS buffers); 5 (all of the LDS, one more stage of lookahead) measured no faster
 constexpr int GROW = 512;   // bytes per token row in LDS
 
 // buffer -> LDS DMA of 16 bytes per lane, written out: through the builtin the compiler sees an LDS store of
@@ -348,17 +348,29 @@ __device__ __forceinline__ void buffer_dma16(const i32x4& rsrc, uint32_t voff, u
                  : "memory", "m0");
 }
 
+// A calibration set arrives as many separately allocated items [tokens_i, K]: the kernel walks a LIST of them (no
+// concatenation copy).  Stages never straddle items: item i owns ceil(tokens_i / GK) stages of the global stage
+// numbering and its rows past the end read as zero through the bounds check of its own buffer descriptor.
+constexpr int kSyrkItems = 128;
+struct SyrkItems {
+    int n;
+    uint32_t stage_start[kSyrkItems + 1];  // prefix sums of the items' stage counts
+    uint32_t bytes[kSyrkItems];            // tokens_i * K * 2
+    const void* x[kSyrkItems];
+};
+
 template <int DT>
-__global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const void* __restrict__ x, int64_t T, int64_t K,
-                                                 float alpha, int ntile, int64_t rows_per_split) {
+__global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const SyrkItems items, int64_t K, float alpha,
+                                                 int ntile, int stages_per_split) {
     extern __shared__ __attribute__((aligned(1024))) char smem16[];  // [GST][A, B][GK * GROW]
     const PairId id = decode_block(ntile);
     const int ti = id.ti, tj = id.tj;
     const bool diag = ti == tj;
     const int64_t i0 = (int64_t)ti * GB, j0 = (int64_t)tj * GB;
-    const int64_t t_begin = (int64_t)id.split * rows_per_split;
-    const int64_t t_end = t_begin + rows_per_split < T ? t_begin + rows_per_split : T;
-    if (t_begin >= t_end) return;
+    const int s_all = (int)items.stage_start[items.n];
+    const int s_begin = id.split * stages_per_split;
+    const int s_end = s_begin + stages_per_split < s_all ? s_begin + stages_per_split : s_all;
+    if (s_begin >= s_end) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wi = wave >> 1, wj = wave & 1;
@@ -369,14 +381,18 @@ __global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const vo
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    // this split's rows as a buffer: offsets >= num_records (tokens >= T) read as zero
-    const char* split_base = (const char*)x + t_begin * K * 2;
-    const uint32_t num_records = (uint32_t)((T - t_begin) * K * 2 < 0xffffffffll ? (T - t_begin) * K * 2 : 0xffffffffll);
+    // the item of the stage being requested, as a buffer: offsets >= num_records (tokens past its end) read as zero
+    int cur_item = 0;
     i32x4 rsrc;
-    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)split_base);
-    rsrc[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(((uintptr_t)split_base >> 32) & 0xffffu));  // stride 0
-    rsrc[2] = __builtin_amdgcn_readfirstlane((int)num_records);
-    rsrc[3] = 0x00020000;
+    auto set_item = [&](int it) {
+        const uintptr_t base = (uintptr_t)items.x[it];
+        rsrc[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        rsrc[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((base >> 32) & 0xffffu));  // stride 0
+        rsrc[2] = __builtin_amdgcn_readfirstlane((int)items.bytes[it]);
+        rsrc[3] = 0x00020000;
+    };
+    while ((uint32_t)s_begin >= items.stage_start[cur_item + 1]) ++cur_item;
+    set_item(cur_item);
     // DMA: wave w brings token rows 8w .. 8w+7 of a stage, two rows per instruction
     uint32_t voff[4];
 #pragma unroll
@@ -384,11 +400,16 @@ __global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const vo
         const uint32_t row = 8 * wave + 2 * u + (lane >> 5);
         voff[u] = row * (uint32_t)K * 2u + (uint32_t)((lane & 31) ^ ((row & 3) << 2)) * 16u;
     }
-    const int nst = (int)((t_end - t_begin + GK - 1) / GK);
+    const int nst = s_end - s_begin;
     const uint32_t lds_base = (uint32_t)(uintptr_t)smem16;
-    auto issue = [&](int st) {
+    auto issue = [&](int st) {  // called with st = 0, 1, 2, ... in order
         const uint32_t dst = lds_base + (uint32_t)((st % GST) * (2 * GK * GROW) + 8 * wave * GROW);
-        const uint32_t so = (uint32_t)st * GK * (uint32_t)K * 2u;
+        const uint32_t gst = (uint32_t)(s_begin + st);
+        if (gst >= items.stage_start[cur_item + 1]) {  // wave-uniform
+            do ++cur_item; while (gst >= items.stage_start[cur_item + 1]);
+            set_item(cur_item);
+        }
+        const uint32_t so = (gst - items.stage_start[cur_item]) * GK * (uint32_t)K * 2u;
 #pragma unroll
         for (int u = 0; u < 4; ++u) buffer_dma16(rsrc, voff[u], so + (uint32_t)i0 * 2u, dst + u * 2 * GROW);
         if (!diag) {
@@ -410,14 +431,15 @@ __global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const vo
     // a stage, so that one wave per SIMD never waits for an LDS round trip with an idle matrix pipe.
     auto stage_ready = [&](int st) {  // stage st has landed for everybody; buffer (st - 1) % GST may be overwritten
         const int later = nst - 1 - st < GST - 2 ? nst - 1 - st : GST - 2;  // later stages whose DMAs may be outstanding
-        if (diag) {  // a diagonal block issues 4 DMAs per stage, the others 8
-            if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // a diagonal block issues 4 DMAs per stage, the others 8 (the count must be an immediate)
+        switch (later * (diag ? 4 : 8)) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
         __syncthreads();
         if (st + GST - 1 < nst) issue(st + GST - 1);
@@ -519,6 +541,83 @@ static int mirror(float* h, int64_t k, hipStream_t s, float scale = 1.0f) {
 static int hessian_accumulate_impl(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k, float alpha,
                                    float beta, void* stream, bool do_mirror);
 
+// upper-triangle accumulation of a list of 16-bit items through the 256x256-tile kernel (2048 <= k < 46341, k % 8 == 0)
+static int launch_syrk16b_list(float* h, const wc::SyrkItems& items, int x_dtype, int64_t k, float alpha, hipStream_t s) {
+    using namespace wc;
+    const int nt = (int)((k + GB - 1) / GB);
+    const int64_t prs = (int64_t)nt * (nt + 1) / 2;
+    const int64_t stages = items.stage_start[items.n];
+    if (stages == 0) return NNCF_AMD_OK;
+    // one block per CU at a time -> >= 8 rounds of blocks keep the tail short; >= 32 stages (1024 tokens) per block
+    int64_t sp = prs >= 2048 ? 1 : (2048 + prs - 1) / prs;
+    const int64_t maxsp = (stages + 31) / 32;
+    if (sp > maxsp) sp = maxsp;
+    if (sp > 65535) sp = 65535;
+    const int64_t sps = (stages + sp - 1) / sp;
+    sp = (stages + sps - 1) / sps;
+    constexpr size_t lds_bytes = (size_t)GST * 2 * GK * GROW;  // 131072
+    static OncePerDevice attr_once;
+    if (attr_once.first_on_device() != 0) {
+        if (hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+            attr_once.forget_current();
+            return launch_status("hessian_syrk16b attribute");
+        }
+    }
+    const dim3 grid((unsigned)prs, (unsigned)sp);
+    if (x_dtype == NNCF_AMD_BF16)
+        hipLaunchKernelGGL((k_syrk16b<NNCF_AMD_BF16>), grid, dim3(256), lds_bytes, s, h, items, k, alpha, nt, (int)sps);
+    else
+        hipLaunchKernelGGL((k_syrk16b<NNCF_AMD_F16>), grid, dim3(256), lds_bytes, s, h, items, k, alpha, nt, (int)sps);
+    return launch_status("hessian_syrk16b");
+}
+
+extern "C" int nncf_amd_hessian_accumulate_list(float* h, int n, const void* const* xs_host, const int64_t* tokens_host,
+                                                int x_dtype, int64_t k, float alpha, void* stream) {
+    using namespace wc;
+    if (!h || k <= 0 || n < 0 || (n > 0 && (!xs_host || !tokens_host))) {
+        set_error("hessian_accumulate_list: bad argument (k=%lld n=%d)", (long long)k, n);
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    for (int i = 0; i < n; ++i)
+        if (tokens_host[i] < 0 || (tokens_host[i] > 0 && !xs_host[i])) {
+            set_error("hessian_accumulate_list: item %d: bad pointer or token count", i);
+            return NNCF_AMD_ERR_BAD_ARG;
+        }
+    if (x_dtype != NNCF_AMD_F32 && x_dtype != NNCF_AMD_F16 && x_dtype != NNCF_AMD_BF16) {
+        set_error("hessian_accumulate_list: unsupported dtype %d", x_dtype);
+        return NNCF_AMD_ERR_DTYPE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    bool list_ok = x_dtype != NNCF_AMD_F32 && k >= 2048 && k < 46341 && k % 8 == 0;
+    for (int i = 0; i < n && list_ok; ++i)
+        list_ok = (((uintptr_t)xs_host[i] & 15u) == 0) && tokens_host[i] * k * 2 <= 0xffffffffll;
+    if (!list_ok) {  // shapes the list kernel does not take: item by item through the single-chunk entry
+        for (int i = 0; i < n; ++i) {
+            const int st = hessian_accumulate_impl(h, xs_host[i], x_dtype, tokens_host[i], k, alpha, 1.0f, stream, false);
+            if (st != NNCF_AMD_OK) return st;
+        }
+        return NNCF_AMD_OK;
+    }
+    for (int first = 0; first < n;) {
+        SyrkItems items = {};
+        int j = 0;
+        uint32_t acc = 0;
+        for (; j < kSyrkItems && first + j < n; ++j) {
+            items.x[j] = xs_host[first + j];
+            items.bytes[j] = (uint32_t)(tokens_host[first + j] * k * 2);
+            items.stage_start[j] = acc;
+            acc += (uint32_t)((tokens_host[first + j] + GK - 1) / GK);
+        }
+        items.stage_start[j] = acc;
+        items.n = j;
+        first += j;
+        const int st = launch_syrk16b_list(h, items, x_dtype, k, alpha, s);
+        if (st != NNCF_AMD_OK) return st;
+    }
+    return NNCF_AMD_OK;
+}
+
 extern "C" int nncf_amd_hessian_accumulate(float* h, const void* x, int x_dtype, int64_t tokens, int64_t k, float alpha,
                                            float beta, void* stream) {
     return hessian_accumulate_impl(h, x, x_dtype, tokens, k, alpha, beta, stream, true);
@@ -583,20 +682,21 @@ static int hessian_accumulate_impl(float* h, const void* x, int x_dtype, int64_t
         sp = (tokens + rps - 1) / rps;
         dim3 g16((unsigned)prs, (unsigned)sp);
         if (big) {
-            constexpr size_t lds_bytes = (size_t)GST * 2 * GK * GROW;  // 131072
-            static OncePerDevice attr_once;
-            if (attr_once.first_on_device() != 0) {
-                if (hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-                    hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
-                    attr_once.forget_current();
-                    return launch_status("hessian_syrk16b attribute");
+            if (tokens * k * 2 > 0xffffffffll) {  // one item must fit a 32-bit buffer: cut it into row ranges
+                const int64_t rows = (0xffffffffll / (k * 2)) / GK * GK;
+                for (int64_t t0 = 0; t0 < tokens; t0 += rows) {
+                    const int64_t nrow = tokens - t0 < rows ? tokens - t0 : rows;
+                    int stp = hessian_accumulate_impl(h, (const char*)x + t0 * k * 2, x_dtype, nrow, k, alpha, 1.0f, stream, false);
+                    if (stp != NNCF_AMD_OK) return stp;
                 }
+                return do_mirror ? mirror(h, k, s) : NNCF_AMD_OK;
             }
-            if (x_dtype == NNCF_AMD_BF16)
-                hipLaunchKernelGGL((k_syrk16b<NNCF_AMD_BF16>), g16, dim3(256), lds_bytes, s, h, x, tokens, k, alpha, nt, rps);
-            else
-                hipLaunchKernelGGL((k_syrk16b<NNCF_AMD_F16>), g16, dim3(256), lds_bytes, s, h, x, tokens, k, alpha, nt, rps);
-            int st16 = launch_status("hessian_syrk16b");
+            SyrkItems items = {};
+            items.n = 1;
+            items.x[0] = x;
+            items.bytes[0] = (uint32_t)(tokens * k * 2);
+            items.stage_start[1] = (uint32_t)((tokens + GK - 1) / GK);
+            int st16 = launch_syrk16b_list(h, items, x_dtype, k, alpha, s);
             if (st16 != NNCF_AMD_OK) return st16;
             return do_mirror ? mirror(h, k, s) : NNCF_AMD_OK;
         }

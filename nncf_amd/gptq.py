@@ -56,13 +56,27 @@ class HessianAccumulator:
         symmetrising pass per chunk; `result` scales by 2 / n and mirrors once)."""
         if not self._buf:
             return
-        x = self._buf[0] if len(self._buf) == 1 else torch.cat(self._buf, dim=0)
-        x = x.contiguous()
+        import ctypes
+
         self.nsamples += self._buf_bs
-        with torch.cuda.device(x.device):
-            st = _lib.lib().nncf_amd_hessian_accumulate_upper(_lib.ptr(self.H), _lib.ptr(x), _lib.dtype_id(x),
-                                                              x.shape[0], self.k, 1.0, 1.0, _lib.stream_of(x))
-        _lib.check(st)
+        first = self._buf[0]
+        if len(self._buf) > 1 and first.dtype != torch.float32 and self.k >= 2048:
+            # the MFMA kernel walks the list of items itself: no concatenation copy (20 ms per Llama-3-70B layer)
+            items = [b.contiguous() for b in self._buf]
+            n = len(items)
+            xs = (ctypes.c_void_p * n)(*[b.data_ptr() for b in items])
+            tk = (ctypes.c_int64 * n)(*[b.shape[0] for b in items])
+            with torch.cuda.device(first.device):
+                st = _lib.lib().nncf_amd_hessian_accumulate_list(_lib.ptr(self.H), n, xs, tk, _lib.dtype_id(first), self.k,
+                                                                 1.0, _lib.stream_of(first))
+            _lib.check(st)
+        else:
+            x = first if len(self._buf) == 1 else torch.cat(self._buf, dim=0)
+            x = x.contiguous()
+            with torch.cuda.device(x.device):
+                st = _lib.lib().nncf_amd_hessian_accumulate_upper(_lib.ptr(self.H), _lib.ptr(x), _lib.dtype_id(x),
+                                                                  x.shape[0], self.k, 1.0, 1.0, _lib.stream_of(x))
+            _lib.check(st)
         self._buf, self._buf_tokens, self._buf_bs = [], 0, 0
         self._final = False
 

@@ -487,6 +487,34 @@ def test_hinv_full_size_property():
     assert float(R.abs().max()) < 2e-4, float(R.abs().max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_hessian_item_list_kernel(dtype):
+    """nncf_amd_hessian_accumulate_list: the MFMA kernel walks a list of separately allocated, ragged calibration
+    items (token counts that are not multiples of its 32-token stage, a 1-token item, > 128 items = two launches)
+    against the fp64 sum, through the C ABI and through HessianAccumulator (which no longer concatenates)."""
+    import ctypes
+    from nncf_amd import _lib, gptq as G
+    K = 2304
+    torch.manual_seed(4)
+    toks = [37, 1, 64, 100, 33] * 27  # 135 items
+    xs = [torch.randn(t, K, device="cuda").to(dtype) for t in toks]
+    ref = sum(x.double().T @ x.double() for x in xs)
+    H = torch.zeros(K, K, device="cuda")
+    n = len(xs)
+    c_x = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+    c_t = (ctypes.c_int64 * n)(*toks)
+    _lib.check(_lib.lib().nncf_amd_hessian_accumulate_list(_lib.ptr(H), n, c_x, c_t, _lib.dtype_id(xs[0]), K, 1.0,
+                                                           _lib.stream_of(H)))
+    _lib.check(_lib.lib().nncf_amd_hessian_finalize(_lib.ptr(H), K, 1.0, _lib.stream_of(H)))
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(H.double(), ref, rtol=1e-5, atol=1e-6 * scale)
+    assert torch.equal(H, H.T)
+    acc = G.HessianAccumulator(K, xs[0].device)
+    for x in xs:
+        acc.add(x, 1)
+    torch.testing.assert_close(acc.result().double(), ref * (2.0 / n), rtol=1e-5, atol=1e-6 * scale * 2 / n)
+
+
 def test_hessian_chunking_equals_item_by_item():
     """HessianAccumulator: one SYRK launch per ~32k buffered tokens == the item-by-item running average."""
     from nncf_amd import gptq as G
