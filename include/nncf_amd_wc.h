@@ -274,6 +274,23 @@ int nncf_amd_se_importance(const float* weight, const float* s_per_channel, cons
                            int mode, float* importance, void* stream);
 
 /*
+ * AWQ alpha-grid search (AWQ._data_aware_step, src/nncf/quantization/algorithms/weight_compression/awq.py:297-352):
+ * for every outlier group g and every candidate scale vector s = 0..steps-1
+ *     wq = gweight_g * scale[g, s];  dq = per-row quantize-dequantize(wq)  (one quantization group per row, :337-341)
+ *     partial[g, s, tile] = sum over the rows of a 16-row tile and the samples of |dq @ sacts[g, s] - fp_out[g]|
+ * in ONE launch; the host sums the tiles (fixed order) and divides by rows * n_samples to get cur_diff (:345).
+ *   weight: fp32, rows of pitch row_pitch; group_offsets (DEVICE int64 [groups]): element offset of the group's first
+ *   column in row 0 (+ the expert offset for 3-D weights);  scales: fp32 [groups, steps, group_size] (cur_scale, after
+ *   the clamp of :315-335);  sacts: fp32 [groups, steps, group_size, 16, NT] = gacts[k][t*16 + c] / scale[k] (:342) with
+ *   NT = 1 / 2 / 4 sample tiles for n_samples <= 16 / 32 / 64, zero beyond the samples;  fp_out: fp32
+ *   [groups, rows, n_samples] (:307);  partial: fp32 [groups, steps, ceil(rows / 16)].
+ * group_size in {32, 64, 128}, n_samples <= 64 (nncf_amd_se_step_supported).
+ */
+int nncf_amd_awq_search(const float* weight, int64_t rows, int64_t row_pitch, const int64_t* group_offsets, int groups,
+                        int64_t group_size, const float* scales, int steps, const float* sacts, const float* fp_out,
+                        int64_t n_samples, int mode, float* partial, void* stream);
+
+/*
  * Token mean of a LIST of separately allocated activation samples x_i[tokens_i, hidden] (one calibration item each):
  * the per-item MeanReducer of the statistics the data-aware algorithms consume (WCTensorStatistic.mean_values,
  * src/nncf/quantization/algorithms/weight_compression/gptq.py:381-396; MeanReducer collectors.py:512-518), two

@@ -59,6 +59,8 @@ SIGNATURES = {
                                  c_void_p]),
     "nncf_amd_se_importance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                        c_int, c_void_p, c_void_p]),
+    "nncf_amd_awq_search": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_int64, c_int, c_void_p, c_void_p]),
     "nncf_amd_decompress": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "nncf_amd_token_mean_workspace": (c_size_t, [c_int, c_int64, c_int64]),
     "nncf_amd_token_mean_batched": (c_int, [c_int, POINTER(c_void_p), c_int, POINTER(c_int64), c_int64, c_void_p, c_void_p,

@@ -552,3 +552,215 @@ extern "C" int nncf_amd_se_importance(const float* weight, const float* s_per_ch
     }
     return launch_status("se_importance");
 }
+
+// ====================================================================================================================
+// AWQ alpha-grid search (awq.py:297-352), every outlier group and every alpha step in ONE launch.  The reference walks
+// the groups and, per group, 100 candidate scales cur = clip(s_g)^alpha; per candidate:
+//     wq = gweight * cur  ->  per-channel quantize-dequantize (one quantization group per row of the [N, gs] slice)
+//     cur_out = dq @ (gacts / cur[:, None]);   cur_diff = mean |cur_out - fp32_out|
+// (~10 launches and ~1 GB of traffic per group on a Llama down_proj).  Here a wave keeps 16 rows of the group's weight
+// slice in registers (lane = row x quarter, as in k_se_step), and for each of its alpha steps scales them, reduces
+// min/max over the row (4 lanes), quantizes, and multiplies by the pre-divided activations on the fp32 MFMA; what
+// leaves the kernel is one partial sum of |cur_out - fp32_out| per (group, step, 16-row tile), summed by the host in
+// a fixed order (no atomics: the argmin over alpha must not depend on the order of a floating-point reduction).
+namespace wc {
+
+struct AwqArgs {
+    const float* w;        // [.., rows, K] fp32, row pitch K
+    const int64_t* goff;   // [groups] element offset of (row 0, first column) of each group's slice
+    const float* scales;   // [groups, steps, GS] candidate scales
+    const float* sacts;    // [groups, steps, GS, 16, NT] = gacts[k][t*16 + c] / scale[k]  (zero beyond the samples)
+    const float* fp_out;   // [groups, rows, ns] = gweight @ gacts
+    float* partial;        // [groups, steps, tiles] sums of |cur_out - fp32_out| over a 16-row tile
+    int64_t rows, K;
+    int steps, ns, mode, steps_per_block;
+};
+
+template <int M>
+__device__ __forceinline__ void awq_stat_xor(const IntPolicyT<M>&, typename IntPolicyT<M>::Stat& s, int mask) {
+    s.lo = fminf(s.lo, __shfl_xor(s.lo, mask, 64));
+    s.hi = fmaxf(s.hi, __shfl_xor(s.hi, mask, 64));
+}
+template <bool NF4, int M>
+__device__ __forceinline__ void awq_stat_xor(const FloatPolicy<NF4, M>&, typename FloatPolicy<NF4, M>::Stat& s, int mask) {
+    s.amax = fmaxf(s.amax, __shfl_xor(s.amax, mask, 64));
+}
+
+template <typename Policy, int GS, int NT>
+__global__ __launch_bounds__(256) void k_awq_search(AwqArgs a) {
+    constexpr int QUART = GS / 4, SP = GS + 4;
+    __shared__ __align__(16) float stage_all[4 * 16 * SP];
+    __shared__ float lut[kPolicyLds];
+    Policy::init_shared(lut);
+    __syncthreads();
+    GroupArgs ga = {};
+    ga.mode = a.mode;
+    const Policy pol(ga, lut);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* stage = stage_all + wave * 16 * SP;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t N = a.rows;
+    const int g = blockIdx.z;
+    const int64_t tiles = (N + 15) / 16;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile >= tiles) return;  // (no block barrier below)
+    const int64_t n0 = tile * 16;
+    const int s_begin = blockIdx.y * a.steps_per_block;
+    const int s_end = s_begin + a.steps_per_block < a.steps ? s_begin + a.steps_per_block : a.steps;
+    // rows n0 .. n0+15 of the group's [rows, GS] slice (row pitch K): se_load_rows addresses base + (gbase + n*G)*GS
+    float wv[QUART];
+    {
+        const float* base = a.w + a.goff[g];
+        constexpr int LPR = GS / 4, RPI = 64 / LPR, NLD = 16 / RPI;
+        const int lr = lane / LPR, lc = (lane % LPR) * 4;
+#pragma unroll
+        for (int t = 0; t < NLD; ++t) {
+            const int64_t gr = n0 + t * RPI + lr;
+            const int64_t grc = gr < N ? gr : N - 1;
+            const float* src = base + grc * a.K + lc;
+            float4 v;
+            if ((((uintptr_t)src) & 15u) == 0) {
+                v = *(const float4*)src;
+            } else {
+                v.x = src[0], v.y = src[1], v.z = src[2], v.w = src[3];
+            }
+            *(float4*)(stage + (t * RPI + lr) * SP + lc) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const float* src = stage + r * SP + q * QUART;
+#pragma unroll
+        for (int i = 0; i < QUART / 4; ++i) {
+            const float4 x = *(const float4*)(src + 4 * i);
+            wv[4 * i] = x.x, wv[4 * i + 1] = x.y, wv[4 * i + 2] = x.z, wv[4 * i + 3] = x.w;
+        }
+    }
+    // fp32_out of this tile in the accumulator layout: rows 4q + i, sample column t*16 + r
+    const float* fo = a.fp_out + (int64_t)g * N * a.ns;
+    float fpv[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t orow = n0 + 4 * q + i;
+            const int col = t * 16 + r;
+            fpv[t][i] = (col < a.ns && orow < N) ? fo[orow * a.ns + col] : 0.0f;
+        }
+    constexpr int C = QUART < 8 ? QUART : 8;
+    for (int s = s_begin; s < s_end; ++s) {
+        const float* sc = a.scales + ((int64_t)g * a.steps + s) * GS + q * QUART;
+        float wq[QUART];
+        typename Policy::Stat st = pol.stat_init();
+#pragma unroll
+        for (int i = 0; i < QUART; i += 4) {
+            const float4 c4 = *(const float4*)(sc + i);
+            wq[i] = wv[i] * c4.x, wq[i + 1] = wv[i + 1] * c4.y, wq[i + 2] = wv[i + 2] * c4.z, wq[i + 3] = wv[i + 3] * c4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < QUART; ++i) pol.stat_add(st, wq[i]);
+        awq_stat_xor(pol, st, 16);
+        awq_stat_xor(pol, st, 32);
+        const typename Policy::Par par = pol.compute(st);
+#pragma unroll
+        for (int c0 = 0; c0 < QUART; c0 += C) {
+            float val[C];
+            se_values<C>(pol, par, wq + c0, val);
+#pragma unroll
+            for (int i = 0; i < C; ++i) wq[c0 + i] = pol.dq(0, val[i], par);
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* xb = a.sacts + (((int64_t)g * a.steps + s) * GS + q * QUART) * 16 * NT + r * NT;
+#pragma unroll
+        for (int p = 0; p < QUART; ++p) {
+            float b[4];
+            if constexpr (NT == 4) {
+                const float4 x = *(const float4*)(xb + p * 16 * NT);
+                b[0] = x.x, b[1] = x.y, b[2] = x.z, b[3] = x.w;
+            } else if constexpr (NT == 2) {
+                const float2 x = *(const float2*)(xb + p * 16 * NT);
+                b[0] = x.x, b[1] = x.y;
+            } else {
+                b[0] = xb[p * 16 * NT];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[p], b[t], acc[t], 0, 0, 0);
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool live = (t * 16 + r) < a.ns && (n0 + 4 * q + i) < N;
+                sum += live ? fabsf(acc[t][i] - fpv[t][i]) : 0.0f;
+            }
+        sum = lanes_allreduce<64>(sum, OpAdd());
+        if (lane == 0) a.partial[((int64_t)g * a.steps + s) * tiles + tile] = sum;
+    }
+}
+
+template <typename Policy, int GS>
+static int awq_launch(const AwqArgs& a, int groups, hipStream_t s) {
+    const int64_t tiles = (a.rows + 15) / 16;
+    const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)((a.steps + a.steps_per_block - 1) / a.steps_per_block), (unsigned)groups);
+    if (a.ns <= 16)
+        hipLaunchKernelGGL((k_awq_search<Policy, GS, 1>), grid, dim3(256), 0, s, a);
+    else if (a.ns <= 32)
+        hipLaunchKernelGGL((k_awq_search<Policy, GS, 2>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_awq_search<Policy, GS, 4>), grid, dim3(256), 0, s, a);
+    return launch_status("awq_search");
+}
+
+template <typename Policy>
+static int awq_gs(const AwqArgs& a, int groups, int64_t gs, hipStream_t s) {
+    switch (gs) {
+        case 32: return awq_launch<Policy, 32>(a, groups, s);
+        case 64: return awq_launch<Policy, 64>(a, groups, s);
+        case 128: return awq_launch<Policy, 128>(a, groups, s);
+        default:
+            set_error("awq_search: group size %lld is not one of 32 / 64 / 128", (long long)gs);
+            return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace wc
+
+extern "C" int nncf_amd_awq_search(const float* weight, int64_t rows, int64_t row_pitch, const int64_t* group_offsets,
+                                   int groups, int64_t group_size, const float* scales, int steps, const float* sacts,
+                                   const float* fp_out, int64_t n_samples, int mode, float* partial, void* stream) {
+    using namespace wc;
+    if (rows < 0 || groups < 0 || steps < 0 || row_pitch < group_size) {
+        set_error("awq_search: bad argument");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (rows == 0 || groups == 0 || steps == 0) return NNCF_AMD_OK;
+    if (!weight || !group_offsets || !scales || !sacts || !fp_out || !partial) {
+        set_error("awq_search: NULL buffer");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (!nncf_amd_se_step_supported(group_size, n_samples) || groups > 65535) {
+        set_error("awq_search: group size %lld / %lld samples / %d groups not supported", (long long)group_size,
+                  (long long)n_samples, groups);
+        return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+    if (((uintptr_t)scales | (uintptr_t)sacts) & 15u) {
+        set_error("awq_search: scales / sacts must be 16-byte aligned");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    // enough blocks to fill the chip: split the alpha steps of a tile over blocks when there are few row tiles
+    const int64_t tiles = (rows + 15) / 16;
+    const int64_t blocks_per_chunk = ((tiles + 3) / 4) * groups;
+    int chunks = (int)((2048 + blocks_per_chunk - 1) / blocks_per_chunk);
+    if (chunks < 1) chunks = 1;
+    if (chunks > steps) chunks = steps;
+    AwqArgs a = {weight, group_offsets, scales, sacts, fp_out, partial, rows, row_pitch, steps, (int)n_samples, mode,
+                 (steps + chunks - 1) / chunks};
+    hipStream_t s = (hipStream_t)stream;
+    if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) return awq_gs<IntPolicy>(a, groups, group_size, s);
+    if (mode == NNCF_AMD_NF4) return awq_gs<FloatPolicy<true>>(a, groups, group_size, s);
+    if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) return awq_gs<FloatPolicy<false>>(a, groups, group_size, s);
+    set_error("awq_search: unsupported mode %d", mode);
+    return NNCF_AMD_ERR_MODE;
+}

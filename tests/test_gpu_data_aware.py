@@ -406,6 +406,32 @@ def test_gptq_against_the_independent_autogptq_reference(golden):
         assert np.isclose(g[f"weight_{e}"], host(q)).mean() >= 0.99
 
 
+@pytest.mark.parametrize("mode,gs,n_samples", [("int4_sym", 128, 32), ("int4_asym", 64, 40), ("nf4", 32, 9), ("int8_asym", 128, 64)])
+def test_fused_awq_search_equals_per_group_path(mode, gs, n_samples):
+    """nncf_amd_awq_search (all groups x alpha steps in one launch) against the per-group torch path (scaled weights
+    -> fused QDQ launch -> bmm -> mean |diff|) with and without the merged previous matmul: the same winning scale
+    on (nearly) every channel; the two sum |cur_out - fp32_out| in different orders, so a step whose error ties with
+    the best one within fp32 noise may win on one side only."""
+    from nncf_amd import awq
+    N, K, Kp = 300, 1024, 256
+    w, stats = _se_case((N, K), n_samples, seed=21)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    prev = torch.randn(K, Kp, device="cuda", generator=g)
+    _, pstats = _se_case((4, Kp), n_samples, seed=22)
+    for m in pstats.mean_values:
+        m *= 30.0
+    for kw in ({}, dict(prev_weight=prev, prev_statistics=pstats)):
+        a = awq.data_aware_step(w, (1,), _cfg(mode, gs), stats, -1, 64, 0.01, 0.0, 1.0, 25, **kw)
+        awq.FUSED_SEARCH = False
+        try:
+            b = awq.data_aware_step(w, (1,), _cfg(mode, gs), stats, -1, 64, 0.01, 0.0, 1.0, 25, **kw)
+        finally:
+            awq.FUSED_SEARCH = True
+        assert a.shape == b.shape and bool((a != 1).any())
+        same = torch.isclose(a, b, rtol=1e-6, atol=0).float().mean()
+        assert float(same) >= 0.9, float(same)
+
+
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 63, 64, 65, 100, 127, 128])
 def test_cholinv_block_kernel(n):
     """nncf_amd_cholinv_block (one workgroup, n <= 128) vs fp64 cholesky + triangular inverse: the block is a
