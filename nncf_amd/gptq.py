@@ -199,6 +199,34 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
     return Q, out_scales, out_zps
 
 
+def quantize_node_weight(weight: torch.Tensor, inputs: List[torch.Tensor], config: WeightCompressionConfig,
+                         reduction_axes=(1,), damp_percent: float = 0.1, block_size: int = 128,
+                         scale_estimation: bool = False):
+    """The per-node body of GPTQ.apply (gptq.py:136-169) for a 2-D [out, in] or 3-D / MoE [experts, out, in] weight:
+    Hessian(s) of the node's inputs, then `quantize_weights` per expert with that expert's Hessian and inputs
+    (`inp[batch_idx]`, :157), results stacked on a leading axis.  Returns (quantized fp32 weight, scale,
+    zero_point | None) shaped like the reference's CompressedWeight parameters."""
+    config = as_config(config)
+    _lib.require_gpu(weight, "quantize_node_weight")
+    is_3d = weight.ndim == 3
+    if weight.ndim not in (2, 3) or tuple(reduction_axes) != ((2,) if is_3d else (1,)):
+        raise UnsupportedModelError("nncf_amd GPTQ expects an [(experts,) out, in] weight reduced along its last axis")
+    w32 = weight.to(torch.float32)
+    hessian = calculate_hessian(inputs, is_3d)
+    wb = w32 if is_3d else w32.unsqueeze(0)
+    qs, scs, zps = [], [], []
+    for b in range(hessian.shape[0]):
+        xs = [inp[b] for inp in inputs] if is_3d else inputs
+        q, sc, zp = quantize_weights(hessian[b], wb[b].contiguous().clone(), config, xs, damp_percent, block_size,
+                                     scale_estimation, (1,))
+        qs.append(q)
+        scs.append(sc)
+        zps.append(zp)
+    if not is_3d:
+        return qs[0], scs[0], zps[0]
+    return torch.stack(qs), torch.stack(scs), (torch.stack(zps) if None not in zps else None)
+
+
 SUPER_BLOCKS = 8  # 128-column blocks per far trailing update (see quantize_weights)
 
 

@@ -475,9 +475,13 @@ def compress_weights_packed_batched(weights, config: WeightCompressionConfig, wa
         return []
     ws = [_prep_weight(w, "compress_weights_packed_batched") for w in weights]
     dev, dt = ws[0].device, ws[0].dtype
+    # 3-D / MoE weights [experts, out, in] are lowered as the [experts * out, in] matrix they are in memory (groups
+    # run along the last axis); the parameters get the expert axis back below
+    lead = [tuple(w.shape[:-1]) for w in ws]
+    ws = [w.reshape(-1, w.shape[-1]) if w.ndim == 3 else w for w in ws]
     for w in ws:
         if w.ndim != 2 or w.device != dev or w.dtype != dt:
-            raise InternalError("compress_weights_packed_batched: 2-D weights of one dtype on one device expected")
+            raise InternalError("compress_weights_packed_batched: 2-D / 3-D weights of one dtype on one device expected")
         if config.group_size != -1 and w.shape[1] % config.group_size != 0:
             msg = f"Channel size {w.shape[1]} should be divisible by size of group {config.group_size}."
             raise InvalidGroupSizeError(msg)
@@ -518,7 +522,12 @@ def compress_weights_packed_batched(weights, config: WeightCompressionConfig, wa
                                                    _lib.MODE_ID[config.mode.value], c_out, c_scale, c_aux, stream)
     _lib.check(st)
     res = []
-    for o, s, a in zip(outs, scales, auxs):
+    for o, s, a, ld in zip(outs, scales, auxs, lead):
+        if len(ld) == 2:  # [experts, out]: parameters [experts, out, G, 1] (or [experts, out, 1]); 8-bit codes likewise
+            s = s.reshape(ld + tuple(s.shape[1:]))
+            a = a.reshape(ld + tuple(a.shape[1:])) if a is not None else None
+            if not four:
+                o = o.reshape(ld + tuple(o.shape[1:]))
         if asym:
             res.append(CompressedWeight(o, s, a))
         else:

@@ -555,3 +555,29 @@ def test_hessian_chunking_equals_item_by_item():
     torch.testing.assert_close(H, acc.result(), rtol=1e-5, atol=1e-6 * scale)
     ref = sum(x[0].double().T @ x[0].double() for x in xs) * 2 / len(xs)
     torch.testing.assert_close(H.double(), ref, rtol=1e-5, atol=1e-6 * scale)
+
+
+@pytest.mark.parametrize("mode,gs", [("int4_sym", 16), ("int4_asym", 32), ("nf4", -1)])
+def test_gptq_node_3d_weight_vs_oracle(mode, gs):
+    """GPTQ on a 3-D / MoE weight [experts, out, in] (gptq.py:136-169: one Hessian per expert from `inp[expert]`, results
+    stacked): Hessians against the oracle, and per expert the column sweep against the oracle's given the same Hinv."""
+    from nncf_amd import gptq
+    E, N, K, T = 3, 24, 128, 96
+    torch.manual_seed(6)
+    w = torch.randn(E, N, K, device="cuda") * 0.05
+    xs = [torch.randn(E, T, K, device="cuda") for _ in range(4)]
+    q, s, z = gptq.quantize_node_weight(w, xs, _cfg(mode, gs), (2,))
+    G = 1 if gs == -1 else K // gs
+    assert tuple(q.shape) == (E, N, K) and tuple(s.shape) == ((E, N, G, 1) if gs != -1 else (E, N, 1))
+    H = gptq.calculate_hessian(xs, is_3d_weight=True)
+    ref_H = O.gptq_hessian([host(x) for x in xs], is_3d_weight=True)
+    np.testing.assert_allclose(host(H), ref_H, rtol=1e-5, atol=1e-6 * np.abs(ref_H).max())
+    for e in range(E):
+        U, dead = gptq.prepare_hinv(H[e].clone(), 0.1)
+        q_ref, s_ref, z_ref = O.gptq_quantize_weights(None, host(w[e]).copy(), mode, gs, hinv=host(U), dead=host(dead))
+        close = np.isclose(host(q[e]), q_ref, rtol=1e-4, atol=1e-7)
+        assert close.mean() >= 0.99, close.mean()
+        assert np.isclose(host(s[e]), s_ref, rtol=2e-5, atol=0).mean() >= 0.99
+        if z_ref is not None:
+            assert (host(z[e]) == z_ref).mean() >= 0.99
+    assert (z is None) == (mode != "int4_asym")

@@ -377,3 +377,29 @@ def test_batched_error_metric_vs_oracle_and_single(mode, gs, reduction, dtype):
     from nncf_amd import errors
     with pytest.raises(errors.InvalidGroupSizeError):
         wl.get_integer_quantization_errors([torch.zeros(4, 30, device="cuda")], [(1,)], _cfg("int4_sym", 16), "max_mean")
+
+
+@pytest.mark.parametrize("mode,gs", [("int4_sym", 64), ("int4_asym", 32), ("int8_asym", -1), ("nf4", 32), ("mxfp4", 32)])
+def test_batched_lowering_of_3d_moe_weights(mode, gs):
+    """compress_weights_packed_batched with 3-D / MoE weights [experts, out, in] mixed with 2-D ones: codes, scales and
+    zero points equal the oracle's compress_weight on the 3-D tensor reduced along its last axis."""
+    from nncf_amd import weight_lowering as wl
+    rng = np.random.default_rng(8)
+    ws32 = [representable((rng.standard_normal(s) * 0.05).astype(np.float32), "bf16") for s in [(4, 24, 256), (16, 512), (2, 7, 128)]]
+    got = wl.compress_weights_packed_batched([to_dev(w, "bf16") for w in ws32], _cfg(mode, gs))
+    for w32, cw in zip(ws32, got):
+        rc, rs, rz = O.compress_weight(w32, (w32.ndim - 1,), mode, gs)
+        assert tuple(cw.scale.shape) == rs.shape
+        assert_equal_nan(host(cw.scale), rs, "scale")
+        if rz is not None:
+            assert_equal_nan(host(cw.zero_point), rz, "zp")
+        if mode.startswith("int8"):
+            assert_equal_nan(host(cw.tensor), rc.reshape(tuple(cw.tensor.shape)), "codes")
+        elif mode.startswith("int4"):
+            ref = O.pack_uint4(rc) if mode == "int4_asym" else O.pack_int4(rc)
+            assert_equal_nan(host(cw.tensor).ravel(), ref.ravel(), "packed")
+        else:
+            p = host(cw.tensor).ravel()
+            codes = np.stack([p & 15, p >> 4], -1).ravel()
+            lut = O.NF4_QUANTILES if mode == "nf4" else O.E2M1_VALUE_OF_CODE
+            assert np.array_equal(lut[codes], rc.ravel())
