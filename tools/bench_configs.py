@@ -124,11 +124,73 @@ def c4(args):
             "weight_GBps_bf16_in": round(sum(a * b for a, b in shapes.values()) * 2 / total / 1e6, 2)}
 
 
+def cpu_baseline(which):
+    """CPU leg of the data-aware configurations: the oracle (oracle/wc_oracle.py, a numpy port of the reference's
+    chain; numpy's BLAS threads) timed on a REDUCED sample of the layer and extrapolated with the stated operation
+    counts -- a reported baseline next to the GPU figure, not a measurement of the full layer."""
+    import os
+
+    import numpy as np
+
+    from oracle import wc_oracle as O
+
+    rng = np.random.default_rng(0)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "16"))
+    if which == "c3":
+        H, I, n = 4096, 14336, 128
+        rows = 64  # rows of every weight that are timed; scale estimation and the AWQ search are linear in the rows
+        means_h = [rng.standard_normal(H).astype(np.float32) for _ in range(n)]
+        means_i = [rng.standard_normal(I).astype(np.float32) for _ in range(n)]
+        sh_h, sh_i = [(1, 2048, H)] * n, [(1, 2048, I)] * n
+        t0 = time.perf_counter()
+        O.scale_estimation_params(means_h, sh_h, (rng.standard_normal((rows, H)) * 0.02).astype(np.float32), (1,), "int4_asym", 128,
+                                  -1, 64, 5, 5)
+        t_se_h = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.scale_estimation_params(means_i, sh_i, (rng.standard_normal((rows, I)) * 0.02).astype(np.float32), (1,), "int4_asym", 128,
+                                  -1, 64, 5, 5)
+        t_se_i = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.awq_data_aware_scale((rng.standard_normal((rows, I)) * 0.02).astype(np.float32), 1, "int4_asym", 128, means_i, sh_i)
+        t_awq = time.perf_counter() - t0
+        out_rows_h = 4096 + 1024 + 1024 + 4096 + 14336 + 14336  # rows of the six weights with K = 4096
+        se_s = t_se_h * out_rows_h / rows + t_se_i * 4096 / rows
+        awq_s = t_awq * 4096 / rows
+        return {"kind": "port", "cores": threads, "sample": f"{rows} rows of every weight of the layer, extrapolated linearly in the rows",
+                "scale_estimation_s_per_layer": round(se_s, 2), "awq_search_s_per_layer": round(awq_s, 2),
+                "layer_s": round(se_s + awq_s, 2)}
+    K, N, T = 1024, 256, 4096
+    xs = [rng.standard_normal((1, T // 2, K)).astype(np.float32) for _ in range(2)]
+    O.gptq_hessian([x[:, :64] for x in xs])  # BLAS thread start-up stays untimed
+    t0 = time.perf_counter()
+    Hm = O.gptq_hessian(xs)[0]
+    t_h = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hinv, dead = O.gptq_hinv(Hm.copy(), 0.1)
+    t_inv = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.gptq_quantize_weights(None, (rng.standard_normal((N, K)) * 0.02).astype(np.float32), "int4_sym", 64, hinv=hinv, dead=dead)
+    t_sw = time.perf_counter() - t0
+    # one Llama-3-70B layer: Hessians and Hinv of K = 8192 (x3) and 28672 (x1) over 262144 tokens; sweeps of the 7 weights
+    tok = 128 * 2048
+    hes = t_h * sum(k * k * tok for k in (8192, 8192, 8192, 28672)) / (K * K * T)
+    inv = t_inv * sum(k ** 3 for k in (8192, 8192, 8192, 28672)) / K ** 3
+    shapes = [(8192, 8192), (1024, 8192), (1024, 8192), (8192, 8192), (28672, 8192), (28672, 8192), (8192, 28672)]
+    sw = t_sw * sum(n_ * k * k for n_, k in shapes) / (N * K * K)
+    return {"kind": "port", "cores": threads, "sample": f"K = {K}, N = {N}, T = {T}; Hessian ~ T K^2, Hinv ~ K^3, sweeps ~ N K^2",
+            "hessian_s_per_layer": round(hes, 1), "hinv_s_per_layer": round(inv, 1), "sweeps_s_per_layer": round(sw, 1),
+            "layer_s": round(hes + inv + sw, 1)}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("which", choices=["c3", "c4"])
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--tokens", type=int, default=2048)
     ap.add_argument("--mode", default="int4_sym")
+    ap.add_argument("--cpu-baseline", action="store_true", help="add the oracle's CPU time on a reduced sample, extrapolated")
     a = ap.parse_args()
-    print(json.dumps({"c3": c3, "c4": c4}[a.which](a)), flush=True)
+    res = {"c3": c3, "c4": c4}[a.which](a)
+    if a.cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(a.which)
+    print(json.dumps(res), flush=True)
