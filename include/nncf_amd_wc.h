@@ -250,28 +250,32 @@ int nncf_amd_se_estimate(const float* weight, const float* importance, int64_t n
 /*
  * One whole search step of scale estimation for a weight (scale_estimation.py:268-360), fused: candidate scale ->
  * quantize -> ideal-scale estimate (`near`) -> quantize-dequantize with `near` -> output error of every group against
- * the cached fp_outs (the [group_size x n_samples] activation slice sits in LDS, the contraction runs on the fp32 MFMA)
- * -> the reference's masked blends of best_diffs / result_scale.
- *   weight, importance: fp32 [batch, rows, groups, group_size] (grouped view of the [rows, groups*group_size] weight);
+ * fp_outs (the [group_size x n_samples] activation slice sits in LDS, the contraction runs on the fp32 MFMA) -> the
+ * reference's masked blends of best_diffs / result_scale.
+ *   weight: [batch, rows, groups, group_size] in its own dtype (NNCF_AMD_F32 or NNCF_AMD_BF16), the grouped view of
+ *   the [rows, groups*group_size] weight, 16-byte aligned;
+ *   zero_mask, rden: from nncf_amd_se_zero_mask (the importance of :236-247 as 1 bit per element + 1 / (sum + eps)
+ *   per group);  s_per_channel: fp32 [batch, groups*group_size] (process_stats' s);
  *   x: fp32 [batch, groups, group_size, n_samples] (process_stats' X, grouped, :249);
- *   fp_outs: fp32 [batch, groups, rows, n_samples] = matmul(moveaxis(weight, -2, -3), x) (:250);
+ *   fp_outs: fp32 [batch, groups, rows, n_samples] = matmul(moveaxis(weight, -2, -3), x) (:250): WRITTEN by kind 0,
+ *   read by kinds 1 and 2;
  *   scale0 (the min-max scale), zero_point (fp32, NULL for symmetric / float modes), best_diffs, result_scale:
  *   fp32 [batch, rows, groups].
- *   kind 0: near = scale0, best_diffs = diff, result_scale = scale0 (the min-max baseline, :252-262);
+ *   kind 0: near = scale0, best_diffs = diff, result_scale = scale0 (the min-max baseline, :252-262), fp_outs written;
  *   kind 1: candidate = result_scale (rectification step, :268-298); kind 2: candidate = factor * scale0 (grid step,
  *   :300-360); both update best_diffs / result_scale in place.  weight_penalty <= 0 disables the penalty term.
  * group_size in {32, 64, 128}, 1 <= n_samples <= 64 (nncf_amd_se_step_supported); other shapes take the unfused path
- * of the host mirror.  nncf_amd_se_importance writes the normalised importance (:236-247) from the per-channel
- * statistic s [batch, groups*group_size].
+ * of the host mirror.
  */
 int nncf_amd_se_step_supported(int64_t group_size, int64_t n_samples);
-int nncf_amd_se_step(const float* weight, const float* importance, const float* x, const float* fp_outs,
-                     const float* scale0, const float* zero_point, float* best_diffs, float* result_scale,
-                     int64_t batch, int64_t rows, int64_t groups, int64_t group_size, int64_t n_samples, int mode,
-                     int kind, float factor, float zero_scale, float weight_penalty, void* stream);
-int nncf_amd_se_importance(const float* weight, const float* s_per_channel, const float* scale0,
-                           const float* zero_point, int64_t batch, int64_t rows, int64_t groups, int64_t group_size,
-                           int mode, float* importance, void* stream);
+int nncf_amd_se_zero_mask(const void* weight, int w_dtype, const float* s_per_channel, const float* scale0,
+                          const float* zero_point, int64_t batch, int64_t rows, int64_t groups, int64_t group_size,
+                          int mode, uint32_t* zero_mask, float* rden, void* stream);
+int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t* zero_mask, const float* rden,
+                     const float* s_per_channel, const float* x, float* fp_outs, const float* scale0,
+                     const float* zero_point, float* best_diffs, float* result_scale, int64_t batch, int64_t rows,
+                     int64_t groups, int64_t group_size, int64_t n_samples, int mode, int kind, float factor,
+                     float zero_scale, float weight_penalty, void* stream);
 
 /*
  * AWQ alpha-grid search (AWQ._data_aware_step, src/nncf/quantization/algorithms/weight_compression/awq.py:297-352):

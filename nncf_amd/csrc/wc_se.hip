@@ -113,14 +113,16 @@ namespace wc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SeStepArgs {
-    const float* w;        // [batch, rows, groups, GS]
-    const float* imp;      // same shape (unused by kind 0)
-    const float* x;        // [batch, groups, GS, ns]
-    const float* fp_outs;  // [batch, groups, rows, ns]
-    const float* scale0;   // [batch, rows, groups] min-max scale
-    const float* zp;       // same shape or NULL
-    float* best;           // same shape, in/out (out only for kind 0)
-    float* result;         // same shape, in/out (out only for kind 0)
+    const void* w;          // [batch, rows, groups, GS] in the weight's own dtype (fp32 or bf16)
+    const uint32_t* zmask;  // [batch, rows, groups, 4]: bit i of word q = "min-max target of element q*GS/4 + i is zero"
+    const float* rden;      // [batch, rows, groups] = 1 / (sum of the unmasked s + eps)
+    const float* s;         // [batch, groups * GS] per-channel activation magnitude
+    const float* x;         // [batch, groups, GS, ns]
+    float* fp_outs;         // [batch, groups, rows, ns]: written by kind 0, read by kinds 1 and 2
+    const float* scale0;    // [batch, rows, groups] min-max scale
+    const float* zp;        // same shape or NULL
+    float* best;            // same shape, in/out (out only for kind 0)
+    float* result;          // same shape, in/out (out only for kind 0)
     int64_t rows, groups;
     int ns, mode, kind;
     float factor, zero_scale, weight_penalty;
@@ -158,31 +160,34 @@ __device__ __forceinline__ void se_values(const FloatPolicy<NF4, M>& pol, const 
     }
 }
 
-// 16 rows of one group, coalesced (whole 4*GS-byte row segments per load instruction) -> registers of the lane that
-// owns the quarter row (lane % 16 = row, lane / 16 = quarter), through the wave's staging buffer.
-// The group of row n starts at base + (gbase + n * G) * GS.
-template <int GS>
-__device__ __forceinline__ void se_load_rows(const float* __restrict__ base, float (&out)[GS / 4], float* stage, int64_t n0,
+// 16 rows of one group, coalesced (whole row segments per load instruction, 16 bytes per lane) -> registers of the
+// lane that owns the quarter row (lane % 16 = row, lane / 16 = quarter), through the wave's staging buffer (raw
+// bytes, row pitch + 16 B), upcast to fp32 on the way out.  The group of row n starts at element (gbase + n * G) * GS.
+template <int GS, int DT>
+__device__ __forceinline__ void se_load_rows(const void* __restrict__ base, float (&out)[GS / 4], float* stage_f, int64_t n0,
                                              int64_t N, int64_t gbase, int64_t G, int lane) {
-    constexpr int QUART = GS / 4, SP = GS + 4, LPR = GS / 4, RPI = 64 / LPR, NLD = 16 / RPI;
+    constexpr int EB = Elem<DT>::kBytes, EPV = Elem<DT>::kPerVec;  // bytes per element, elements per 16-byte vector
+    constexpr int QUART = GS / 4, PITCH = GS * EB + 16, LPR = GS / EPV, RPI = 64 / LPR, NLD = 16 / RPI;
+    static_assert(NLD >= 1 && QUART % EPV == 0, "group size too small for this dtype");
+    char* stage = (char*)stage_f;
     const int r = lane & 15, q = lane >> 4;
-    const int lr = lane / LPR, lc = (lane % LPR) * 4;
-    float4 v[NLD];
+    const int lr = lane / LPR, lc = (lane % LPR) * 16;  // row inside the instruction, byte offset inside the row
+    Vec16 v[NLD];
 #pragma unroll
     for (int t = 0; t < NLD; ++t) {
         const int64_t gr = n0 + t * RPI + lr;
         const int64_t grc = gr < N ? gr : N - 1;
-        v[t] = *(const float4*)(base + (gbase + grc * G) * GS + lc);
+        v[t] = *(const Vec16*)((const char*)base + (gbase + grc * G) * GS * EB + lc);
     }
 #pragma unroll
-    for (int t = 0; t < NLD; ++t) *(float4*)(stage + (t * RPI + lr) * SP + lc) = v[t];
+    for (int t = 0; t < NLD; ++t) *(Vec16*)(stage + (t * RPI + lr) * PITCH + lc) = v[t];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const float* src = stage + r * SP + q * QUART;
+    const char* src = stage + r * PITCH + q * QUART * EB;
 #pragma unroll
-    for (int i = 0; i < QUART / 4; ++i) {
-        const float4 x = *(const float4*)(src + 4 * i);
-        out[4 * i] = x.x, out[4 * i + 1] = x.y, out[4 * i + 2] = x.z, out[4 * i + 3] = x.w;
+    for (int i = 0; i < QUART / EPV; ++i) {
+        const Vec16 x = *(const Vec16*)(src + 16 * i);
+        unpack<DT>(x, out + EPV * i);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -192,17 +197,18 @@ constexpr int kSeWaves = 12;  // 133 KiB of LDS: one block per CU, three waves p
 constexpr int kSeThreads = kSeWaves * 64;
 template <int GS>
 constexpr int se_lds_floats() {
-    return GS * 64 + kSeWaves * 16 * (GS + 4) + kSeWaves * 16 + kPolicyLds;
+    return GS * 64 + kSeWaves * 16 * (GS + 4) + kSeWaves * 16 + GS + kPolicyLds;
 }
 
 // NT: 16-sample tiles of the MFMA (1, 2 or 4)
-template <typename Policy, int GS, int NT>
+template <typename Policy, int DT, int GS, int NT>
 __global__ __launch_bounds__(kSeThreads) void k_se_step(SeStepArgs a) {
     constexpr int QUART = GS / 4;  // elements a lane owns
     constexpr int SP = GS + 4;     // pitch (floats) of a staged row: +16 B
     extern __shared__ __align__(16) float se_smem[];
     float* Xs = se_smem;  // [GS][16 columns][4 tiles]: sample column j of row k at k*64 + (j%16)*4 + j/16
-    float* lut = Xs + GS * 64 + kSeWaves * 16 * SP + kSeWaves * 16;
+    float* ssh = Xs + GS * 64 + kSeWaves * 16 * SP + kSeWaves * 16;  // per-channel activation magnitudes of the group
+    float* lut = ssh + GS;
     Policy::init_shared(lut);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* stage = Xs + GS * 64 + wave * 16 * SP;
@@ -225,13 +231,14 @@ __global__ __launch_bounds__(kSeThreads) void k_se_step(SeStepArgs a) {
             }
         }
     }
+    if (threadIdx.x < GS) ssh[threadIdx.x] = a.kind != 0 ? a.s[(e * G + g) * GS + threadIdx.x] : 0.0f;
     __syncthreads();
     GroupArgs ga = {};
     ga.mode = a.mode;
     const Policy pol(ga, lut);
     const int r = lane & 15, q = lane >> 4;
     const bool has_zp = a.zp != nullptr;
-    const float* fo = a.fp_outs + ((e * G + g) * N) * ns;
+    float* fo = a.fp_outs + ((e * G + g) * N) * ns;
     // a block serves ONE group column g (its X slice stays in LDS) and every gridDim.x-th set of four 16-row tiles
     for (int64_t n0 = ((int64_t)blockIdx.x * kSeWaves + wave) * 16; n0 < N; n0 += (int64_t)gridDim.x * kSeWaves * 16) {
         const int64_t row = n0 + r;
@@ -240,29 +247,63 @@ __global__ __launch_bounds__(kSeThreads) void k_se_step(SeStepArgs a) {
         const float sc0 = a.scale0[pidx];
         const float zpf = has_zp ? a.zp[pidx] : 0.0f;
         float wv[QUART];
-        se_load_rows<GS>(a.w, wv, stage, n0, N, (e * N) * G + g, G, lane);
+        se_load_rows<GS, DT>(a.w, wv, stage, n0, N, (e * N) * G + g, G, lane);
         float near = sc0;
         constexpr int C = QUART < 8 ? QUART : 8;
+        // kind 0 also produces fp_outs = w @ X (scale_estimation.py:250) for the later steps, on the same MFMA path
+        f32x4 facc[NT];
+        if (a.kind == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) facc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const float* xrow0 = Xs + (q * QUART) * 64 + r * 4;
+#pragma unroll
+            for (int p = 0; p < QUART; ++p) {
+                float b[4];
+                if constexpr (NT == 4) {
+                    const float4 x = *(const float4*)(xrow0 + p * 64);
+                    b[0] = x.x, b[1] = x.y, b[2] = x.z, b[3] = x.w;
+                } else {
+                    const float2 x = *(const float2*)(xrow0 + p * 64);
+                    b[0] = x.x, b[1] = x.y;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) facc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[p], b[t], facc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t orow = n0 + 4 * q + i;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int col = t * 16 + r;
+                    if (col < ns && orow < N) fo[orow * ns + col] = facc[t][i];
+                }
+            }
+        }
         if (a.kind != 0) {
-            float iv[QUART];
-            se_load_rows<GS>(a.imp, iv, stage, n0, N, (e * N) * G + g, G, lane);
+            // importance_k = (mask_k ? 0 : s_k) / (sum + eps)  (scale_estimation.py:236-247): the sum over the group of
+            // ideal_k * s_k is taken over the unmasked elements and scaled by 1 / (sum + eps) once
+            const uint32_t mw = a.zmask[pidx * 4 + q];
+            const float rd = a.rden[pidx];
             const float cand = a.kind == 1 ? a.result[pidx] : a.factor * sc0;
             const typename Policy::Par pc = se_par(pol, cand, zpf, has_zp);
             float acc = 0.0f;
 #pragma unroll
             for (int c0 = 0; c0 < QUART; c0 += C) {
-                float val[C];
+                float val[C], sch[C];
                 se_values<C>(pol, pc, wv + c0, val);
+#pragma unroll
+                for (int i = 0; i < C; i += 4) *(float4*)(sch + i) = *(const float4*)(ssh + q * QUART + c0 + i);
 #pragma unroll
                 for (int i = 0; i < C; ++i) {
                     const float target = pol.target(val[i], pc);
                     const float zm = fabsf(target) <= 1e-8f ? a.zero_scale : 0.0f;  // isclose(target, 0): atol 1e-8
-                    acc += fabsf(wv[c0 + i]) / (fabsf(target) + zm) * iv[c0 + i];
+                    const float sv = ((mw >> (c0 + i)) & 1u) ? 0.0f : sch[i];
+                    acc += fabsf(wv[c0 + i]) / (fabsf(target) + zm) * sv;
                 }
             }
             acc += __shfl_xor(acc, 16, 64);
             acc += __shfl_xor(acc, 32, 64);
-            near = acc * (sc0 / fabsf(sc0));  // scale_sign = scale / |scale|  (scale_estimation.py:264)
+            near = (acc * rd) * (sc0 / fabsf(sc0));  // scale_sign = scale / |scale|  (scale_estimation.py:264)
         }
         // quantize-dequantize with `near`, in place; optional weight penalty
         const typename Policy::Par pn = se_par(pol, near, zpf, has_zp);
@@ -294,11 +335,9 @@ __global__ __launch_bounds__(kSeThreads) void k_se_step(SeStepArgs a) {
             if constexpr (NT == 4) {
                 const float4 x = *(const float4*)(xrow + p * 64);
                 b[0] = x.x, b[1] = x.y, b[2] = x.z, b[3] = x.w;
-            } else if constexpr (NT == 2) {
+            } else {
                 const float2 x = *(const float2*)(xrow + p * 64);
                 b[0] = x.x, b[1] = x.y;
-            } else {
-                b[0] = xrow[p * 64];
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[p], b[t], acc[t], 0, 0, 0);
@@ -312,7 +351,9 @@ __global__ __launch_bounds__(kSeThreads) void k_se_step(SeStepArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = t * 16 + r;
-                const float f = (col < ns && orow < N) ? fo[orow * ns + col] : 0.0f;
+                float f;
+                if (a.kind == 0) f = (col < ns && orow < N) ? facc[t][i] : 0.0f;
+                else f = (col < ns && orow < N) ? fo[orow * ns + col] : 0.0f;
                 const float d = f - acc[t][i];
                 sum += (col < ns) ? d * d : 0.0f;
             }
@@ -345,85 +386,55 @@ __global__ __launch_bounds__(kSeThreads) void k_se_step(SeStepArgs a) {
     }
 }
 
-// importance of scale estimation (scale_estimation.py:236-247): s per input channel, zero where the min-max
-// quantization's target is ~0, normalised per group.  16 lanes per group.
-template <typename Policy>
-__global__ __launch_bounds__(256) void k_se_importance(const float* __restrict__ w, const float* __restrict__ s, GroupArgs a,
-                                                       int64_t gs, int64_t groups_per_row, int64_t rows, float* __restrict__ imp) {
+// Zero mask + normaliser of the importance (scale_estimation.py:236-247): importance_k = (target0_k ~ 0 ? 0 : s_k) /
+// (sum + eps) with target0 the min-max quantization.  Instead of the importance (4 B per element, re-read by every
+// step) the steps get 1 bit per element (word q of a group = its q-th quarter) and 1 / (sum + eps) per group.
+// One lane per 16-byte vector of the weight (consecutive lanes read consecutive vectors); gs in {32, 64, 128}.
+template <typename Policy, int DT>
+__global__ __launch_bounds__(256) void k_se_zero_mask(const void* __restrict__ w, const float* __restrict__ s, GroupArgs a,
+                                                      int gs, int64_t groups_per_row, int64_t rows,
+                                                      uint32_t* __restrict__ zmask, float* __restrict__ rden) {
+    constexpr int E = Elem<DT>::kPerVec, EB = Elem<DT>::kBytes;
     __shared__ float lds[kPolicyLds];
     Policy::init_shared(lds);
     __syncthreads();
     const Policy pol(a, lds);
-    const int l = threadIdx.x & 15;
-    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-    const bool live = g < a.n_groups;
-    const int64_t gg = live ? g : a.n_groups - 1;
+    const int lpg = gs / E, lpq = lpg >> 2, quart = gs >> 2;  // lanes per group / per quarter (powers of two, lpq >= 1)
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx / lpg < a.n_groups;
+    const int64_t gg = live ? idx / lpg : a.n_groups - 1;  // idle lanes shadow the last group (they take part in the reductions)
+    const int l = (int)(idx % lpg), q = l / lpq, bit0 = l * E - q * quart;
     const typename Policy::Par par = pol.load(a, gg);
-    const float* wg = w + gg * gs;
-    // s is [batch, groups_per_row * gs]; group gg belongs to batch gg / (rows * groups_per_row), column group gg % groups_per_row
-    const float* sg = s + ((gg / (rows * groups_per_row)) * groups_per_row + gg % groups_per_row) * gs;
-    float* ig = imp + gg * gs;
+    const float* sg = s + ((gg / (rows * groups_per_row)) * groups_per_row + gg % groups_per_row) * gs + l * E;
+    float f[E], sv[E];
+    unpack<DT>(*(const Vec16*)((const char*)w + (gg * gs + (int64_t)l * E) * EB), f);
+#pragma unroll
+    for (int i = 0; i < E; i += 4) *(float4*)(sv + i) = *(const float4*)(sg + i);
+    uint32_t bits = 0;
     float sum = 0.0f;
-    if (gs <= 256 && (gs & 63) == 0 && ((((uintptr_t)w | (uintptr_t)s | (uintptr_t)imp) & 15u) == 0)) {
-        // 16 lanes x float4 per 64 elements, values kept in registers between the two passes
-        float v[16];
-        const int nq = (int)(gs >> 6);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (u < nq) {
-                const float4 wq = *(const float4*)(wg + u * 64 + l * 4);
-                const float4 sq = *(const float4*)(sg + u * 64 + l * 4);
-                const float win[4] = {wq.x, wq.y, wq.z, wq.w}, sin[4] = {sq.x, sq.y, sq.z, sq.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int code;
-                    float val;
-                    pol.quant(win[i], par, code, val);
-                    const float target = pol.target(val, par);
-                    v[4 * u + i] = fabsf(target) <= 1e-8f ? 0.0f : sin[i];
-                    sum += v[4 * u + i];
-                }
-            }
-        }
-        sum = lanes_allreduce<16>(sum, OpAdd());
-        const float den = sum + kEps;
-        if (!live) return;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (u < nq)
-                *(float4*)(ig + u * 64 + l * 4) = make_float4(v[4 * u] / den, v[4 * u + 1] / den, v[4 * u + 2] / den, v[4 * u + 3] / den);
-        }
-        return;
-    }
-    for (int64_t k = l; k < gs; k += 16) {
+    for (int i = 0; i < E; ++i) {
         int code;
         float val;
-        pol.quant(wg[k], par, code, val);
-        const float target = pol.target(val, par);
-        const float v = fabsf(target) <= 1e-8f ? 0.0f : sg[k];
-        sum += v;
+        pol.quant(f[i], par, code, val);
+        const bool zero = fabsf(pol.target(val, par)) <= 1e-8f;  // isclose(target, 0): atol 1e-8
+        bits |= zero ? (1u << (bit0 + i)) : 0u;
+        sum += zero ? 0.0f : sv[i];
     }
-    sum = lanes_allreduce<16>(sum, OpAdd());
-    const float den = sum + kEps;
+    for (int m = 1; m < lpq; m <<= 1) bits |= (uint32_t)__shfl_xor((int)bits, m, 64);
+    for (int m = 1; m < lpg; m <<= 1) sum += __shfl_xor(sum, m, 64);
     if (!live) return;
-    for (int64_t k = l; k < gs; k += 16) {
-        int code;
-        float val;
-        pol.quant(wg[k], par, code, val);
-        const float target = pol.target(val, par);
-        const float v = fabsf(target) <= 1e-8f ? 0.0f : sg[k];
-        ig[k] = v / den;
-    }
+    if (l % lpq == 0) zmask[gg * 4 + q] = bits;
+    if (l == 0) rden[gg] = 1.0f / (sum + kEps);
 }
 
-template <typename Policy, int GS>
+template <typename Policy, int DT, int GS>
 static int se_step_launch(const SeStepArgs& a, int64_t batch, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)se_lds_floats<GS>() * sizeof(float);
     static OncePerDevice attr_once;
     if (attr_once.first_on_device() != 0) {
-        if (hipFuncSetAttribute((const void*)k_se_step<Policy, GS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_se_step<Policy, GS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_se_step<Policy, GS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_se_step<Policy, DT, GS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_se_step<Policy, DT, GS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
             attr_once.forget_current();
             return launch_status("se_step attribute");
         }
@@ -435,25 +446,31 @@ static int se_step_launch(const SeStepArgs& a, int64_t batch, hipStream_t s) {
     if (per_col > tile_sets) per_col = tile_sets;
     if (per_col < 1) per_col = 1;
     const dim3 grid((unsigned)per_col, (unsigned)a.groups, (unsigned)batch);
-    if (a.ns <= 16)
-        hipLaunchKernelGGL((k_se_step<Policy, GS, 1>), grid, dim3(kSeThreads), lds_bytes, s, a);
-    else if (a.ns <= 32)
-        hipLaunchKernelGGL((k_se_step<Policy, GS, 2>), grid, dim3(kSeThreads), lds_bytes, s, a);
+    if (a.ns <= 32)
+        hipLaunchKernelGGL((k_se_step<Policy, DT, GS, 2>), grid, dim3(kSeThreads), lds_bytes, s, a);
     else
-        hipLaunchKernelGGL((k_se_step<Policy, GS, 4>), grid, dim3(kSeThreads), lds_bytes, s, a);
+        hipLaunchKernelGGL((k_se_step<Policy, DT, GS, 4>), grid, dim3(kSeThreads), lds_bytes, s, a);
     return launch_status("se_step");
 }
 
-template <typename Policy>
+template <typename Policy, int DT>
 static int se_step_gs(const SeStepArgs& a, int64_t batch, int64_t gs, hipStream_t s) {
     switch (gs) {
-        case 32: return se_step_launch<Policy, 32>(a, batch, s);
-        case 64: return se_step_launch<Policy, 64>(a, batch, s);
-        case 128: return se_step_launch<Policy, 128>(a, batch, s);
+        case 32: return se_step_launch<Policy, DT, 32>(a, batch, s);
+        case 64: return se_step_launch<Policy, DT, 64>(a, batch, s);
+        case 128: return se_step_launch<Policy, DT, 128>(a, batch, s);
         default:
             set_error("se_step: group size %lld is not one of 32 / 64 / 128", (long long)gs);
             return NNCF_AMD_ERR_UNSUPPORTED;
     }
+}
+
+template <typename Policy>
+static int se_step_dt(const SeStepArgs& a, int w_dtype, int64_t batch, int64_t gs, hipStream_t s) {
+    if (w_dtype == NNCF_AMD_F32) return se_step_gs<Policy, NNCF_AMD_F32>(a, batch, gs, s);
+    if (w_dtype == NNCF_AMD_BF16) return se_step_gs<Policy, NNCF_AMD_BF16>(a, batch, gs, s);
+    set_error("se_step: weight dtype %d (fp32 and bf16 are taken; upcast fp16 first)", w_dtype);
+    return NNCF_AMD_ERR_DTYPE;
 }
 
 }  // namespace wc
@@ -462,17 +479,19 @@ extern "C" int nncf_amd_se_step_supported(int64_t group_size, int64_t n_samples)
     return (group_size == 32 || group_size == 64 || group_size == 128) && n_samples >= 1 && n_samples <= 64;
 }
 
-extern "C" int nncf_amd_se_step(const float* weight, const float* importance, const float* x, const float* fp_outs,
-                                const float* scale0, const float* zero_point, float* best_diffs, float* result_scale,
-                                int64_t batch, int64_t rows, int64_t groups, int64_t group_size, int64_t n_samples,
-                                int mode, int kind, float factor, float zero_scale, float weight_penalty, void* stream) {
+extern "C" int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t* zero_mask, const float* rden,
+                                const float* s_per_channel, const float* x, float* fp_outs, const float* scale0,
+                                const float* zero_point, float* best_diffs, float* result_scale, int64_t batch,
+                                int64_t rows, int64_t groups, int64_t group_size, int64_t n_samples, int mode, int kind,
+                                float factor, float zero_scale, float weight_penalty, void* stream) {
     using namespace wc;
     if (batch < 0 || rows < 0 || groups < 0 || kind < 0 || kind > 2) {
         set_error("se_step: bad argument");
         return NNCF_AMD_ERR_BAD_ARG;
     }
     if (batch * rows * groups == 0) return NNCF_AMD_OK;
-    if (!weight || !x || !fp_outs || !scale0 || !best_diffs || !result_scale || (kind != 0 && !importance)) {
+    if (!weight || !x || !fp_outs || !scale0 || !best_diffs || !result_scale ||
+        (kind != 0 && (!zero_mask || !rden || !s_per_channel))) {
         set_error("se_step: NULL buffer");
         return NNCF_AMD_ERR_BAD_ARG;
     }
@@ -485,12 +504,12 @@ extern "C" int nncf_amd_se_step(const float* weight, const float* importance, co
         set_error("se_step: more than 65535 groups per row or batch entries");
         return NNCF_AMD_ERR_UNSUPPORTED;
     }
-    if (((uintptr_t)weight | (uintptr_t)importance) & 15u) {
-        set_error("se_step: weight / importance must be 16-byte aligned");
+    if ((uintptr_t)weight & 15u) {
+        set_error("se_step: weight must be 16-byte aligned");
         return NNCF_AMD_ERR_BAD_ARG;
     }
-    SeStepArgs a = {weight, importance, x, fp_outs, scale0, zero_point, best_diffs, result_scale, rows, groups,
-                    (int)n_samples, mode, kind, factor, zero_scale, weight_penalty};
+    SeStepArgs a = {weight, zero_mask, rden, s_per_channel, x, fp_outs, scale0, zero_point, best_diffs, result_scale,
+                    rows, groups, (int)n_samples, mode, kind, factor, zero_scale, weight_penalty};
     hipStream_t s = (hipStream_t)stream;
     if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
         const bool asym = mode == NNCF_AMD_INT8_ASYM || mode == NNCF_AMD_INT4_ASYM;
@@ -499,27 +518,47 @@ extern "C" int nncf_amd_se_step(const float* weight, const float* importance, co
             return NNCF_AMD_ERR_BAD_ARG;
         }
         if (!asym) a.zp = nullptr;
-        return se_step_gs<IntPolicy>(a, batch, group_size, s);
+        return se_step_dt<IntPolicy>(a, w_dtype, batch, group_size, s);
     }
     a.zp = nullptr;
-    if (mode == NNCF_AMD_NF4) return se_step_gs<FloatPolicy<true>>(a, batch, group_size, s);
-    if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) return se_step_gs<FloatPolicy<false>>(a, batch, group_size, s);
+    if (mode == NNCF_AMD_NF4) return se_step_dt<FloatPolicy<true>>(a, w_dtype, batch, group_size, s);
+    if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) return se_step_dt<FloatPolicy<false>>(a, w_dtype, batch, group_size, s);
     set_error("se_step: unsupported mode %d", mode);
     return NNCF_AMD_ERR_MODE;
 }
 
-extern "C" int nncf_amd_se_importance(const float* weight, const float* s_per_channel, const float* scale0,
-                                      const float* zero_point, int64_t batch, int64_t rows, int64_t groups,
-                                      int64_t group_size, int mode, float* importance, void* stream) {
+template <typename Policy>
+static int se_zero_mask_dt(const void* w, int w_dtype, const float* s, const wc::GroupArgs& a, int gs, int64_t groups,
+                           int64_t rows, uint32_t* zmask, float* rden, hipStream_t st) {
     using namespace wc;
-    if (batch < 0 || rows < 0 || groups < 0 || group_size < 1) {
-        set_error("se_importance: bad argument");
+    const int64_t lanes = a.n_groups * (gs / (w_dtype == NNCF_AMD_F32 ? 4 : 8));
+    const dim3 grid((unsigned)((lanes + 255) / 256));
+    if (w_dtype == NNCF_AMD_F32)
+        hipLaunchKernelGGL((k_se_zero_mask<Policy, NNCF_AMD_F32>), grid, dim3(256), 0, st, w, s, a, gs, groups, rows, zmask, rden);
+    else if (w_dtype == NNCF_AMD_BF16)
+        hipLaunchKernelGGL((k_se_zero_mask<Policy, NNCF_AMD_BF16>), grid, dim3(256), 0, st, w, s, a, gs, groups, rows, zmask, rden);
+    else if (w_dtype == NNCF_AMD_F16)
+        hipLaunchKernelGGL((k_se_zero_mask<Policy, NNCF_AMD_F16>), grid, dim3(256), 0, st, w, s, a, gs, groups, rows, zmask, rden);
+    else {
+        set_error("se_zero_mask: unsupported weight dtype %d", w_dtype);
+        return NNCF_AMD_ERR_DTYPE;
+    }
+    return launch_status("se_zero_mask");
+}
+
+extern "C" int nncf_amd_se_zero_mask(const void* weight, int w_dtype, const float* s_per_channel, const float* scale0,
+                                     const float* zero_point, int64_t batch, int64_t rows, int64_t groups,
+                                     int64_t group_size, int mode, uint32_t* zero_mask, float* rden, void* stream) {
+    using namespace wc;
+    if (batch < 0 || rows < 0 || groups < 0 || (group_size != 32 && group_size != 64 && group_size != 128) ||
+        ((uintptr_t)weight & 15u) || ((uintptr_t)s_per_channel & 15u)) {
+        set_error("se_zero_mask: bad argument (group size 32 / 64 / 128; weight and s_per_channel 16-byte aligned)");
         return NNCF_AMD_ERR_BAD_ARG;
     }
     const int64_t n_groups = batch * rows * groups;
     if (n_groups == 0) return NNCF_AMD_OK;
-    if (!weight || !s_per_channel || !scale0 || !importance) {
-        set_error("se_importance: NULL buffer");
+    if (!weight || !s_per_channel || !scale0 || !zero_mask || !rden) {
+        set_error("se_zero_mask: NULL buffer");
         return NNCF_AMD_ERR_BAD_ARG;
     }
     GroupArgs a = {};
@@ -530,27 +569,23 @@ extern "C" int nncf_amd_se_importance(const float* weight, const float* s_per_ch
     a.gs = group_size;
     a.inner = 1;
     a.mode = mode;
-    const dim3 grid((unsigned)((n_groups * 16 + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
     if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
         const bool asym = mode == NNCF_AMD_INT8_ASYM || mode == NNCF_AMD_INT4_ASYM;
         if (asym && !zero_point) {
-            set_error("se_importance: asymmetric mode needs the zero points");
+            set_error("se_zero_mask: asymmetric mode needs the zero points");
             return NNCF_AMD_ERR_BAD_ARG;
         }
         if (!asym) a.zp_in = nullptr;
-        hipLaunchKernelGGL((k_se_importance<IntPolicy>), grid, dim3(256), 0, st, weight, s_per_channel, a, group_size, groups, rows, importance);
-    } else if (mode == NNCF_AMD_NF4) {
-        a.zp_in = nullptr;
-        hipLaunchKernelGGL((k_se_importance<FloatPolicy<true>>), grid, dim3(256), 0, st, weight, s_per_channel, a, group_size, groups, rows, importance);
-    } else if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) {
-        a.zp_in = nullptr;
-        hipLaunchKernelGGL((k_se_importance<FloatPolicy<false>>), grid, dim3(256), 0, st, weight, s_per_channel, a, group_size, groups, rows, importance);
-    } else {
-        set_error("se_importance: unsupported mode %d", mode);
-        return NNCF_AMD_ERR_MODE;
+        return se_zero_mask_dt<IntPolicy>(weight, w_dtype, s_per_channel, a, (int)group_size, groups, rows, zero_mask, rden, st);
     }
-    return launch_status("se_importance");
+    a.zp_in = nullptr;
+    if (mode == NNCF_AMD_NF4)
+        return se_zero_mask_dt<FloatPolicy<true>>(weight, w_dtype, s_per_channel, a, (int)group_size, groups, rows, zero_mask, rden, st);
+    if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4)
+        return se_zero_mask_dt<FloatPolicy<false>>(weight, w_dtype, s_per_channel, a, (int)group_size, groups, rows, zero_mask, rden, st);
+    set_error("se_zero_mask: unsupported mode %d", mode);
+    return NNCF_AMD_ERR_MODE;
 }
 
 // ====================================================================================================================

@@ -55,7 +55,8 @@ def calculate_quantization_params(
     reduction_axis = reduction_axes[0]
     s, X = process_stats(statistics, subset_size, act_ch_axis=act_ch_axis)
     X = X.to(torch.float32)
-    weight = weight.to(torch.float32)
+    native = weight if weight.dtype in (torch.bfloat16, torch.float32) else weight.to(torch.float32)
+    weight = weight.to(torch.float32) if not FUSED_SEARCH else native  # (the fused search reads bf16 as it is)
     is_3d_weight = weight.ndim == 3
     was_transposed = False
     if reduction_axis == 0 or (reduction_axis == 1 and is_3d_weight):
@@ -72,6 +73,7 @@ def calculate_quantization_params(
         result_scale, zp = _fused_search(weight.contiguous(), s, X, config, group_size, initial_steps, scale_steps,
                                          weight_penalty)
         return _finish(result_scale, zp, config, was_transposed)
+    weight = weight.to(torch.float32)
 
     if not config.is_integer:
         q_weights, compressed_weight = float_quantize_dequantize_weight(weight, cur_config, reduction_axis,
@@ -184,9 +186,11 @@ FUSED_SEARCH = True  # developer switch: False takes the step-by-step path below
 
 
 def _fused_search(weight, s, X, config, group_size, initial_steps, scale_steps, weight_penalty):
-    """The search of scale_estimation.py:236-360 with ONE launch per candidate (nncf_amd_se_step): the weight and the
-    importance are read once per step, nothing weight-sized is written.  weight: fp32 contiguous [(E,) N, K] reduced
-    along the last axis; s: [(E,) K]; X: [(E,) K, n].  Returns (result_scale [(E,) N, G, 1], zp fp32 | None)."""
+    """The search of scale_estimation.py:236-360 with ONE launch per candidate (nncf_amd_se_step): the weight is read
+    once per step in its own dtype, the importance is a 1-bit zero mask + 1 / (sum + eps) per group
+    (nncf_amd_se_zero_mask), fp_outs comes out of the first step; nothing weight-sized is written.  weight: bf16 or
+    fp32, contiguous [(E,) N, K] reduced along the last axis; s: [(E,) K]; X: [(E,) K, n].
+    Returns (result_scale [(E,) N, G, 1], zp fp32 | None)."""
     from nncf_amd.weight_lowering import calculate_float_quantization_params, calculate_integer_quantization_params
 
     lib = _lib.lib()
@@ -205,22 +209,26 @@ def _fused_search(weight, s, X, config, group_size, initial_steps, scale_steps, 
     Xg, _ = reshape_weight_for_grouped_quantization(X, -2, group_size)  # [(E,) G, gs, n]
     Xg = Xg.contiguous()
     n_s = Xg.shape[-1]
-    fp_outs = torch.matmul(torch.movedim(wg, -2, -3), Xg).contiguous()  # [(E,) G, N, n]  (:250)
-    importance = torch.empty_like(wg)
+    lead = tuple(weight.shape[:-2])
+    fp_outs = torch.empty(lead + (G, N, n_s), dtype=torch.float32, device=dev)  # (:250), written by the first step
+    zmask = torch.empty(tuple(scale0.shape[:-1]) + (4,), dtype=torch.int32, device=dev)
+    rden = torch.empty(scale0.shape, dtype=torch.float32, device=dev)
     best = torch.empty(scale0.shape, dtype=torch.float32, device=dev)
     result = torch.empty_like(best)
     mode_id = _lib.MODE_ID[config.mode.value]
+    dt = _lib.dtype_id(weight)
     with torch.cuda.device(dev):
         stream = _lib.stream_of(weight)
-        _lib.check(lib.nncf_amd_se_importance(_lib.ptr(wg), _lib.ptr(s), _lib.ptr(scale0), _lib.ptr(zp), batch, N, G,
-                                              group_size, mode_id, _lib.ptr(importance), stream))
+        _lib.check(lib.nncf_amd_se_zero_mask(_lib.ptr(wg), dt, _lib.ptr(s), _lib.ptr(scale0), _lib.ptr(zp), batch, N, G,
+                                             group_size, mode_id, _lib.ptr(zmask), _lib.ptr(rden), stream))
 
         def step(kind, factor=1.0):
-            _lib.check(lib.nncf_amd_se_step(_lib.ptr(wg), _lib.ptr(importance), _lib.ptr(Xg), _lib.ptr(fp_outs),
-                                            _lib.ptr(scale0), _lib.ptr(zp), _lib.ptr(best), _lib.ptr(result), batch, N, G,
-                                            group_size, n_s, mode_id, kind, factor, 0.001, weight_penalty, stream))
+            _lib.check(lib.nncf_amd_se_step(_lib.ptr(wg), dt, _lib.ptr(zmask), _lib.ptr(rden), _lib.ptr(s), _lib.ptr(Xg),
+                                            _lib.ptr(fp_outs), _lib.ptr(scale0), _lib.ptr(zp), _lib.ptr(best),
+                                            _lib.ptr(result), batch, N, G, group_size, n_s, mode_id, kind, factor, 0.001,
+                                            weight_penalty, stream))
 
-        step(0)  # min-max baseline: best_diffs, result_scale = scale0
+        step(0)  # min-max baseline: fp_outs, best_diffs, result_scale = scale0
         for _ in range(initial_steps):
             step(1)  # candidate = current result_scale
         for scale_step in range(scale_steps):

@@ -297,6 +297,23 @@ def test_fused_se_search_matches_oracle(mode, shape, gs, n_samples, subset):
         assert np.array_equal(host(zp), ref_z)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mode,gs", [("int4_asym", 128), ("int4_sym", 32), ("nf4", 64)])
+def test_fused_se_search_16bit_weights(mode, gs, dtype):
+    """The fused search reads a bf16 weight as it is (no fp32 copy; fp16 is upcast by the host mirror): same result
+    as the oracle on the upcast weight (scale_estimation.py:197 casts to fp32 first)."""
+    from nncf_amd import scale_estimation as SE
+    w, stats = _se_case((260, 512), 48, seed=17)
+    w = w.to(dtype)
+    sc, zp = SE.calculate_quantization_params(stats, w, (1,), _cfg(mode, gs), -1, 64, 5, 5)
+    ref_s, ref_z = O.scale_estimation_params([host(m) for m in stats.mean_values], stats.shape_values, host(w.float()), (1,),
+                                             mode, gs, -1, 64, 5, 5)
+    close = np.isclose(host(sc), ref_s, rtol=1e-5, atol=0)
+    assert close.mean() >= 0.995, close.mean()
+    if ref_z is not None:
+        assert np.array_equal(host(zp), ref_z)
+
+
 @pytest.mark.parametrize("penalty", [-1.0, 0.3])
 @pytest.mark.parametrize("mode,gs", [("int4_asym", 128), ("int4_sym", 64), ("nf4", 32)])
 def test_fused_se_search_equals_stepwise_path(mode, gs, penalty):
