@@ -13,6 +13,7 @@
 // The token axis is split over gridDim.y when there are too few tile pairs to fill 256 CUs; partial products
 // are combined with fp32 atomic adds (H is pre-scaled by beta in a separate pass), so the low-order bits of H
 // can differ from run to run by summation order -- well inside the 1e-5 relative contract.
+#include <type_traits>
 #include "wc_common.h"
 
 namespace wc {
@@ -402,20 +403,29 @@ __global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const Sy
     }
     const int nst = s_end - s_begin;
     const uint32_t lds_base = (uint32_t)(uintptr_t)smem16;
-    auto issue = [&](int st) {  // called with st = 0, 1, 2, ... in order
-        const uint32_t dst = lds_base + (uint32_t)((st % GST) * (2 * GK * GROW) + 8 * wave * GROW);
+    // DMA of stage st (called with st = 0, 1, 2, ... in order): issue_prepare, then issue_one(0 .. n_dma - 1), which
+    // the main loop spreads between its MFMAs
+    const int n_dma = diag ? 4 : 8;
+    uint32_t cur_start = items.stage_start[cur_item], next_start = items.stage_start[cur_item + 1];  // SGPRs: no loads per stage
+    uint32_t dma_dst = 0, dma_so = 0;
+    auto issue_prepare = [&](int st) {
+        dma_dst = lds_base + (uint32_t)((st % GST) * (2 * GK * GROW) + 8 * wave * GROW);
         const uint32_t gst = (uint32_t)(s_begin + st);
-        if (gst >= items.stage_start[cur_item + 1]) {  // wave-uniform
+        if (gst >= next_start) {  // wave-uniform
             do ++cur_item; while (gst >= items.stage_start[cur_item + 1]);
+            cur_start = items.stage_start[cur_item];
+            next_start = items.stage_start[cur_item + 1];
             set_item(cur_item);
         }
-        const uint32_t so = (gst - items.stage_start[cur_item]) * GK * (uint32_t)K * 2u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) buffer_dma16(rsrc, voff[u], so + (uint32_t)i0 * 2u, dst + u * 2 * GROW);
-        if (!diag) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) buffer_dma16(rsrc, voff[u], so + (uint32_t)j0 * 2u, dst + GK * GROW + u * 2 * GROW);
-        }
+        dma_so = (gst - cur_start) * GK * (uint32_t)K * 2u;
+    };
+    auto issue_one = [&](int u) {
+        if (u < 4) buffer_dma16(rsrc, voff[u], dma_so + (uint32_t)i0 * 2u, dma_dst + u * 2 * GROW);
+        else buffer_dma16(rsrc, voff[u - 4], dma_so + (uint32_t)j0 * 2u, dma_dst + GK * GROW + (u - 4) * 2 * GROW);
+    };
+    auto issue = [&](int st) {
+        issue_prepare(st);
+        for (int u = 0; u < n_dma; ++u) issue_one(u);
     };
     // transposing reads: per-lane byte offsets inside a stage image for the 4 m-tiles of this wave's A and B panels
     const int kh = lane >> 5, grp = (lane >> 4) & 1, i16 = lane & 15, r3 = i16 >> 2;
@@ -426,14 +436,29 @@ __global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const Sy
         offa[m] = lane_const + (uint32_t)(wi * 16 + ((m ^ r3) << 2)) * 16u;
         offb[m] = lane_const + (uint32_t)(wj * 16 + ((m ^ r3) << 2)) * 16u + (diag ? 0u : (uint32_t)(GK * GROW));
     }
-    // The MFMA operands of the k-step after the current one are always on their way (register double buffer), also
-    // across the stage boundary: the wait + barrier + DMA issue for the next stage sit between the two k-steps of
-    // a stage, so that one wave per SIMD never waits for an LDS round trip with an idle matrix pipe.
-    auto stage_ready = [&](int st) {  // stage st has landed for everybody; buffer (st - 1) % GST may be overwritten
-        const int later = nst - 1 - st < GST - 2 ? nst - 1 - st : GST - 2;  // later stages whose DMAs may be outstanding
-        // a diagonal block issues 4 DMAs per stage, the others 8 (the count must be an immediate)
-        switch (later * (diag ? 4 : 8)) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    // One wave per SIMD: whenever the wave waits, its matrix pipe idles, so the order of issue is written out.  The
+    // MFMAs are volatile asm (the compiler keeps volatile asm and the LDS reads in source order), and between them go,
+    // one or two at a time, the transposing LDS reads of the NEXT k-step's operands (register double buffer: by the
+    // time the next k-step starts they have been on their way for >= 8 MFMAs) and the DMA instructions of the stage
+    // GST - 1 ahead.  Per stage: k-step 0 [MFMAs + reads of k-step 1 | wait for the next stage's DMAs + barrier |
+    // MFMAs + DMA issue], k-step 1 [MFMAs + reads of the next stage's k-step 0].
+    typedef int op_t __attribute__((ext_vector_type(4)));  // one MFMA operand: 8 16-bit values of one row / column
+    auto read_op = [&](const char* img, uint32_t off, int ks) {
+        struct Pair {
+            s16x4 lo, hi;
+        } p;
+        p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + off + (16 * ks) * GROW));
+        p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + off + (16 * ks + 4) * GROW));
+        return __builtin_bit_cast(op_t, p);
+    };
+    auto mfma = [&](f32x16& c, const op_t& a, const op_t& b) {
+        if constexpr (DT == NNCF_AMD_BF16)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
+        else
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
+    };
+    auto wait_dma = [&](int outstanding) {  // all but the `outstanding` most recent DMAs have landed (immediates)
+        switch (outstanding) {
             case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
             case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
             case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
@@ -441,41 +466,80 @@ __global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const Sy
             case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
-        __syncthreads();
-        if (st + GST - 1 < nst) issue(st + GST - 1);
-    };
-    auto read_ops = [&](int st, int ks, s16x4 (*a)[2], s16x4 (*b)[2]) {
-        const char* img = smem16 + (st % GST) * (2 * GK * GROW);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                a[m][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(img + offa[m] + (16 * ks + 4 * half) * GROW));
-                b[m][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(img + offb[m] + (16 * ks + 4 * half) * GROW));
-            }
-    };
-    auto mma = [&](s16x4 (*a)[2], s16x4 (*b)[2]) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = mfma16<DT>(a[m][0], a[m][1], b[n][0], b[n][1], acc[m][n]);
     };
     static_assert(GK == 32, "two k-steps per stage");
-    for (int st = 0; st < GST - 1 && st < nst; ++st) issue(st);
-    s16x4 a0[4][2], b0[4][2], a1[4][2], b1[4][2];
-    stage_ready(0);
-    read_ops(0, 0, a0, b0);
-    for (int st = 0; st < nst; ++st) {
-        read_ops(st, 1, a1, b1);
-        mma(a0, b0);
-        if (st + 1 < nst) {
-            stage_ready(st + 1);
-            read_ops(st + 1, 0, a0, b0);
+    static_assert(GST >= 3, "the steady state keeps GST - 3 stages in flight behind the one it waits for");
+    constexpr int kBarrierAfter = 7;  // k-step 0: wait + barrier after this MFMA
+    // the DMA instructions of a stage are spread evenly over the gaps behind the barrier (the rest of k-step 0 and
+    // all of k-step 1): bunched together, the four waves' requests queue up in front of the texture addresser and
+    // every queued instruction holds its wave's issue
+    constexpr int kDmaSlots = 16 - (kBarrierAfter + 1) + 16;
+    op_t a0[4], b0[4], a1[4], b1[4];
+    // 16 MFMAs on (ca, cb).  READS: operand j (0..3: A rows, 4..7: B columns) of the next k-step is read after MFMA j.
+    // SYNC (k-step 0 of a stage that has a successor): after MFMA kBarrierAfter wait until all but `outstanding` of
+    // this wave's DMAs have landed, then the barrier (the next stage is in LDS for everybody, the previous stage's
+    // buffer is free).  DMA: NDMA DMA instructions of the stage GST - 1 ahead, one after each of the following MFMAs.
+    auto kstep = [&](const op_t* ca, const op_t* cb, op_t* na, op_t* nb, const char* img, int ks, auto reads, auto sync,
+                     auto ndma, auto slot0, auto steady, int outstanding) {
+        constexpr bool READS = decltype(reads)::value, SYNC = decltype(sync)::value, STEADY = decltype(steady)::value;
+        constexpr int NDMA = decltype(ndma)::value;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            mfma(acc[i >> 2][i & 3], ca[i >> 2], cb[i & 3]);
+            if constexpr (READS) {
+                if (i < 4) na[i] = read_op(img, offa[i], ks);
+                else if (i < 8) nb[i - 4] = read_op(img, offb[i - 4], ks);
+            }
+            if constexpr (SYNC) {
+                if (i == kBarrierAfter) {
+                    if constexpr (STEADY) {
+                        if constexpr (NDMA * (GST - 3) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if constexpr (NDMA * (GST - 3) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else if constexpr (NDMA * (GST - 3) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else {
+                        wait_dma(outstanding);
+                    }
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            if constexpr (NDMA > 0) {  // DMA slot of this gap; piece p goes into slot p * kDmaSlots / NDMA
+                constexpr int SLOT0 = decltype(slot0)::value;
+                const int slot = SLOT0 + i;
+                if (slot >= 0 && slot < kDmaSlots && slot % (kDmaSlots / NDMA) == 0) issue_one(slot / (kDmaSlots / NDMA));
+            }
         }
-        mma(a1, b1);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    for (int st = 0; st < GST - 1 && st < nst; ++st) issue(st);
+    wait_dma((nst - 1 < GST - 2 ? nst - 1 : GST - 2) * n_dma);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        a0[m] = read_op(smem16, offa[m], 0);
+        b0[m] = read_op(smem16, offb[m], 0);
     }
+    auto run = [&](auto ndma) {  // ndma: DMA instructions per stage and wave (4 on a diagonal block, else 8)
+        int st = 0;
+        for (; st + GST - 1 < nst; ++st) {  // steady state: stage st + GST - 1 is requested while stage st is multiplied
+            const char* img = smem16 + (st % GST) * (2 * GK * GROW);
+            issue_prepare(st + GST - 1);
+            kstep(a0, b0, a1, b1, img, 1, T{}, T{}, ndma, std::integral_constant<int, -(kBarrierAfter + 1)>{}, T{}, 0);
+            kstep(a1, b1, a0, b0, smem16 + ((st + 1) % GST) * (2 * GK * GROW), 0, T{}, F{}, ndma, std::integral_constant<int, 16 - (kBarrierAfter + 1)>{}, T{}, 0);
+        }
+        for (; st + 1 < nst; ++st) {  // the last GST - 2 stages with a successor: nothing left to request
+            const char* img = smem16 + (st % GST) * (2 * GK * GROW);
+            kstep(a0, b0, a1, b1, img, 1, T{}, T{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, F{}, (nst - 2 - st) * decltype(ndma)::value);
+            kstep(a1, b1, a0, b0, smem16 + ((st + 1) % GST) * (2 * GK * GROW), 0, T{}, F{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, F{}, 0);
+        }
+        const char* img = smem16 + (st % GST) * (2 * GK * GROW);  // the last stage
+        kstep(a0, b0, a1, b1, img, 1, T{}, F{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, F{}, 0);
+        kstep(a1, b1, a0, b0, img, 0, F{}, F{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, F{}, 0);
+    };
+    if (diag) run(std::integral_constant<int, 4>{});
+    else run(std::integral_constant<int, 8>{});
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs leave the pipe before the read-out
     // epilogue with 32-bit offsets (K < 46341 on this path: K*K fits; checked by the host)
     const uint32_t kl = lane >> 5, cl = lane & 31, Ku = (uint32_t)K;
     const uint32_t bi = (uint32_t)i0 + wi * 128 + 4 * kl, bj = (uint32_t)j0 + wj * 128 + cl;

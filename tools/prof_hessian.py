@@ -11,7 +11,7 @@ from nncf_amd import gptq  # noqa: E402
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 x = torch.randn((1, T, K), device="cuda", dtype=torch.bfloat16)
-for it in range(4):
+for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 4):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     gptq.calculate_hessian([x])
