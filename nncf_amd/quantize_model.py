@@ -521,6 +521,7 @@ class WeightCompression:
         by_name = {wp.module_name: wp for wp in all_params}
         is_data_free = not statistics or not adv.prefer_data_aware_scaling
         scale_per_target: Dict[str, torch.Tensor] = {}
+        self.awq_scale_per_target = {}  # activation scales in the reference's shapes (awq.py:237 _scale_per_target_node)
         # targets in the reference's match order: patterns in registration order (awq_patterns.py:20-69, awq.py:386-421)
         rank = {"mul_linear": 0, "act_mul": 1, "act": 2}
         matched = [wp for wp in all_params if wp.module_name in trace.producer and wp.kind == "matmul"
@@ -556,10 +557,12 @@ class WeightCompression:
                 src_mod = merge_wp.module if merge_wp is not None else _weighted_modules(self._model)[src]
                 src_mod.weight.data = (src_mod.weight.data * a_scale.unsqueeze(red)).to(weight_dtype)
                 # (a bias of the producing Linear is left as it is: awq.py:210-214 scales the weight only)
+                self.awq_scale_per_target[wp.module_name] = a_scale.unsqueeze(red)
             else:  # Act -> [Multiply ->] MatMul: a multiply by 1/scale in front of the Linear (awq.py:215-235)
                 shape = tuple(a_scale.shape[-1] if d == act_ch_axis else 1 for d in range(len(act_shape)))
                 a_scale = a_scale.reshape(shape)
                 insert_sq_multiply(wp.module, a_scale)
+                self.awq_scale_per_target[wp.module_name] = a_scale
             scale_per_target[wp.module_name] = a_scale
         # awq.py:424-432 (out of place: Linears that share an activation share the stored mean tensors here)
         if statistics:
@@ -805,6 +808,7 @@ def compress_weights(model: nn.Module, *, mode=CompressWeightsMode.INT8_ASYM, ra
     finally:
         model.train(was_training)
     model._nncf_amd_weight_compression = algo.bitwidth_report
+    model._nncf_amd_awq_scales = getattr(algo, "awq_scale_per_target", {})
     return model
 
 

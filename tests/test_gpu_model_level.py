@@ -474,3 +474,45 @@ def test_hf_llama_architecture(algo):
         tr = trace_model(_tiny_llama(), data[0], with_provenance=True)
         assert tr.producer["model.layers.0.mlp.down_proj"] == ("mul_linear", "model.layers.0.mlp.up_proj")
         assert not hasattr(model.model.layers[0].mlp.down_proj, "awq_input_scale")
+
+
+class _AwqLinearModel(torch.nn.Module):
+    """The six-Linear model of the reference's AWQ scale test (tests/torch/function_hook/quantization/
+    test_weights_compression.py:208-258), restated: every weight = 0.01 * arange(64).reshape(8, 8) + 0.05; mergeable:
+    linear3 reads linear1(x) * linear2(x) (MatMul -> Multiply -> MatMul), non-mergeable: linear2 reads relu(linear1(x))."""
+
+    def __init__(self, non_mergable_pattern):
+        super().__init__()
+        self.non_mergable_pattern = non_mergable_pattern
+        for i in range(1, 5 if non_mergable_pattern else 7):
+            lin = torch.nn.Linear(8, 8, bias=False)
+            lin.weight = torch.nn.Parameter(0.01 * torch.arange(0, 64, dtype=torch.float32).reshape(8, 8) + 0.05)
+            setattr(self, f"linear{i}", lin)
+
+    def forward(self, x):
+        if self.non_mergable_pattern:
+            return self.linear4(torch.relu(self.linear3(self.linear2(torch.relu(self.linear1(x))))))
+        n3 = self.linear3(self.linear1(x) * self.linear2(x))
+        return self.linear6(self.linear4(n3) * self.linear5(n3))
+
+
+@pytest.mark.parametrize("non_mergable_pattern", [True, False])
+def test_awq_scale_reference_literals(non_mergable_pattern):
+    """The reference's own known answers for the AWQ activation scales (template_test_weights_compression.py:766-803
+    with the Torch literals of tests/torch/function_hook/quantization/test_weights_compression.py:856-884): INT4_SYM,
+    ratio 1, per-channel, two copies of input 0.01 * arange + 0.02, rtol 1e-5 (fns.allclose).  The reference keys are
+    its graph node names ("linear3/linear/0"), ours the module names."""
+    ref = {"linear3": np.array([[1.226455], [1.205499], [1.141340], [1.097436], [1.064355], [1.037971], [1.016118],
+                                [0.997526]], np.float32),
+           "linear2": np.array([[[1.990990, 1.863296, 1.575980, 1.397459, 1.272275, 1.177998, 1.103558, 1.042768]]],
+                               np.float32)}
+    import nncf_amd
+    model = _AwqLinearModel(non_mergable_pattern).cuda()
+    x = torch.from_numpy(0.01 * np.arange(0, 32, dtype=np.float32).reshape(1, 4, 8) + 0.02)
+    nncf_amd.compress_weights(model, mode="int4_sym", ratio=1.0, all_layers=False, group_size=-1,
+                              dataset=nncf_amd.Dataset([x] * 2), awq=True)
+    scales = model._nncf_amd_awq_scales
+    assert set(scales) == {"linear2" if non_mergable_pattern else "linear3"}
+    for name, sc in scales.items():
+        assert tuple(sc.shape) == ref[name].shape
+        np.testing.assert_allclose(sc.cpu().numpy(), ref[name], rtol=1e-5, atol=1e-8)
