@@ -673,6 +673,7 @@ class WeightCompression:
                 if cache:
                     save_statistics(cache, statistics, activation_scores, self._statistics_tag())
             statistics = statistics or None
+        self.activation_scores = activation_scores
         self.apply_mixed_precision(ratio_defining, activation_scores)
         self.validate_group_size(ratio_defining)
         self.bitwidth_report = {wp.module_name: wp.compression_config for wp in all_params + skipped}
@@ -809,6 +810,8 @@ def compress_weights(model: nn.Module, *, mode=CompressWeightsMode.INT8_ASYM, ra
         model.train(was_training)
     model._nncf_amd_weight_compression = algo.bitwidth_report
     model._nncf_amd_awq_scales = getattr(algo, "awq_scale_per_target", {})
+    model._nncf_amd_mixed_precision = {"activation_scores": dict(getattr(algo, "activation_scores", {})),
+                                       "scores": [float(v) for v in getattr(algo, "sensitivity_scores", {}).values()]}
     return model
 
 

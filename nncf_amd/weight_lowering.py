@@ -488,6 +488,10 @@ def compress_weights_packed_batched(weights, config: WeightCompressionConfig, wa
     n = len(ws)
     four = config.num_bits == 4
     asym = config.is_integer and config.is_asym_mode
+    if four and any((config.group_size if config.group_size != -1 else w.shape[1]) % 2 for w in ws) and not want_e8m0:
+        # groups of an odd number of 4-bit codes do not end on a byte: the single-tensor entry packs them from the
+        # byte codes (group size 1 is what the reference's mixed-precision tests use)
+        return [compress_weight_packed(w, (w.ndim - 1,), config) for w in weights]
     outs, scales, auxs = [], [], []
     for w in ws:
         o, i = w.shape

@@ -8,6 +8,7 @@ forward in the fixture, so activations differ in the last bits): the precision a
 within one fp16 ulp on >= 97 % of the groups, codes equal on >= 97 % of the elements, logits close."""
 import hashlib
 import json
+import math
 import os
 
 import numpy as np
@@ -516,3 +517,67 @@ def test_awq_scale_reference_literals(non_mergable_pattern):
     for name, sc in scales.items():
         assert tuple(sc.shape) == ref[name].shape
         np.testing.assert_allclose(sc.cpu().numpy(), ref[name], rtol=1e-5, atol=1e-8)
+
+
+class _SequentialMatmulModel(torch.nn.Module):
+    """Five 4x4 Linears in a row, weight = arange(16).reshape(4, 4) with the last element replaced by 10000, 1000, 1,
+    10, 10000, stored transposed (tests/torch/function_hook/quantization/test_weights_compression.py:67-84, restated)."""
+
+    def __init__(self):
+        super().__init__()
+        self.layers = torch.nn.ModuleList()
+        for main_value in (10000, 1000, 1, 10, 10000):
+            w = torch.arange(0, 16, dtype=torch.float32).reshape(4, 4)
+            w[-1, -1] = main_value
+            layer = torch.nn.Linear(4, 4, bias=False)
+            layer.weight = torch.nn.Parameter(w.t().contiguous())
+            self.layers.append(layer)
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+@pytest.mark.parametrize("metric,all_layers,ratio,ref_ids", [
+    ("weight_quantization_error", True, 1, [0, 1, 2, 3, 4]), ("weight_quantization_error", True, 0.8, [0, 3, 4]),
+    ("weight_quantization_error", True, 0.4, [0]), ("weight_quantization_error", True, 0.2, []),
+    ("weight_quantization_error", False, 1, [0, 1, 2, 3]), ("weight_quantization_error", False, 0.8, [0, 1, 3]),
+    ("weight_quantization_error", False, 0.4, [0]), ("weight_quantization_error", False, 0.2, []),
+    ("hessian_input_activation", True, 0.8, [0, 1, 2]), ("hessian_input_activation", False, 0.8, [0, 1, 2]),
+    ("mean_activation_variance", True, 0.8, [0, 1, 2]), ("mean_activation_variance", False, 0.8, [0, 1, 2]),
+    ("max_activation_variance", True, 0.8, [0, 1, 2]), ("max_activation_variance", False, 0.8, [0, 1, 2]),
+    ("mean_activation_magnitude", True, 0.8, [0, 1, 2]), ("mean_activation_magnitude", False, 0.8, [0, 1, 2])])
+def test_mixed_precision_reference_ids(metric, all_layers, ratio, ref_ids):
+    """The reference's known answers for which Linears end up in INT4 (template_test_weights_compression.py:207-246,
+    transpose_a = False as on its Torch backend): INT4_SYM, group size 1, two samples (ones, arange(16))."""
+    import nncf_amd
+    from nncf_amd.decompressors import INT4SymmetricWeightsDecompressor
+    model = _SequentialMatmulModel().cuda()
+    first = torch.ones((1, 4, 4), dtype=torch.float32)
+    second = torch.arange(16, dtype=torch.float32).reshape(1, 4, 4)
+    nncf_amd.compress_weights(model, mode="int4_sym", ratio=ratio, group_size=1, all_layers=all_layers,
+                              sensitivity_metric=metric, dataset=nncf_amd.Dataset([first, second]))
+    got = [i for i, layer in enumerate(model.layers)
+           if any(isinstance(m, INT4SymmetricWeightsDecompressor) for m in layer.modules())]
+    assert got == ref_ids
+
+
+@pytest.mark.parametrize("metric,ref_act_score,with_baseline", [
+    ("hessian_input_activation", (16 + 1 + 4) * 2 / 9, False), ("mean_activation_magnitude", 2.333333, True),
+    ("mean_activation_variance", 1.555555, True), ("max_activation_variance", 3.555555, True)])
+def test_data_based_criterion_reference_scores(metric, ref_act_score, with_baseline):
+    """template_test_weights_compression.py:147-178: activation [[[-4, 1, 2], [0, 0, 0], [0, 0, 0]]] in front of a
+    255 * eye(3) weight, INT4_ASYM group size 1, ratio 0.5, all layers: the activation sensitivity equals the literal
+    (rel 1e-5) and the weight's score is 0 for the Hessian metric and literal / eps(fp32) for the others."""
+    import nncf_amd
+    model = torch.nn.Linear(3, 3, bias=False)
+    model.weight = torch.nn.Parameter(255 * torch.eye(3, dtype=torch.float32))
+    model = torch.nn.Sequential(model).cuda()
+    x = torch.tensor([[[-4, 1, 2], [0, 0, 0], [0, 0, 0]]], dtype=torch.float32)
+    nncf_amd.compress_weights(model, mode="int4_asym", ratio=0.5, group_size=1, all_layers=True,
+                              sensitivity_metric=metric, dataset=nncf_amd.Dataset([x]))
+    dbg = model._nncf_amd_mixed_precision
+    assert math.isclose(dbg["activation_scores"]["0"], ref_act_score, rel_tol=1e-5, abs_tol=1e-8)
+    ref_score = ref_act_score / 1.1920928955078125e-07 if with_baseline else 0.0
+    assert math.isclose(dbg["scores"][0], ref_score, rel_tol=1e-5, abs_tol=1e-8)
