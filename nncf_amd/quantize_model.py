@@ -585,6 +585,7 @@ class WeightCompression:
                                                              wp.reduction_axes, cfg, act_ch_axis, p.subset_size,
                                                              p.initial_steps, p.scale_steps, p.weight_penalty)
             res[wp.weight_name] = CompressedWeight(None, scale, zp, None)
+        self.se_scales = {k: v.scale for k, v in res.items() if v.scale is not None}  # fp32, as estimated
         return res
 
     # ---- gptq.py:82-171 with a torch layer-wise feeder in place of the OpenVINO-only LayerwiseEngine
@@ -810,6 +811,7 @@ def compress_weights(model: nn.Module, *, mode=CompressWeightsMode.INT8_ASYM, ra
         model.train(was_training)
     model._nncf_amd_weight_compression = algo.bitwidth_report
     model._nncf_amd_awq_scales = getattr(algo, "awq_scale_per_target", {})
+    model._nncf_amd_se_scales = getattr(algo, "se_scales", {})
     model._nncf_amd_mixed_precision = {"activation_scores": dict(getattr(algo, "activation_scores", {})),
                                        "scores": [float(v) for v in getattr(algo, "sensitivity_scores", {}).values()]}
     return model

@@ -581,3 +581,30 @@ def test_data_based_criterion_reference_scores(metric, ref_act_score, with_basel
     assert math.isclose(dbg["activation_scores"]["0"], ref_act_score, rel_tol=1e-5, abs_tol=1e-8)
     ref_score = ref_act_score / 1.1920928955078125e-07 if with_baseline else 0.0
     assert math.isclose(dbg["scores"][0], ref_score, rel_tol=1e-5, abs_tol=1e-8)
+
+
+@pytest.mark.parametrize("sampled", [False, True], ids=["full", "sampled"])
+def test_scale_estimation_reference_literals(sampled):
+    """The reference's known answers for scale estimation at model level (template_test_weights_compression.py:281-326
+    with the Torch literals of tests/torch/function_hook/quantization/test_weights_compression.py:657-700): one
+    Linear(8 -> 16) with weight arange(128).reshape(16, 8), INT4_ASYM group size 8, input arange(32) (+ i for sample
+    i); "sampled": two calibration samples of which scale estimation uses one (the sampling flow of process_stats)."""
+    import nncf_amd
+    ref = ([0.473328, 0.929023, 1.446527, 1.920595, 2.517054, 3.030102, 3.584279, 4.043509, 4.620008, 5.165322, 5.710637,
+            6.122581, 6.655914, 7.237174, 7.722580, 8.255914],
+           [0.473445, 0.928777, 1.446328, 1.920052, 2.516778, 3.029870, 3.584271, 4.042929, 4.619769, 5.165224, 5.710679,
+            6.121212, 6.654546, 7.236652, 7.721212, 8.254545])[sampled]
+    lin = torch.nn.Linear(8, 16, bias=False)
+    lin.weight = torch.nn.Parameter(torch.arange(0, 8 * 16, dtype=torch.float32).reshape(16, 8))
+    model = torch.nn.Sequential(lin).cuda()
+    x = torch.arange(0, 4 * 8, dtype=torch.float32).reshape(1, 4, 8)
+    subset = 2 if sampled else 1
+    se_subset = subset // 2 if sampled else subset
+    nncf_amd.compress_weights(
+        model, mode="int4_asym", ratio=1.0, group_size=8, scale_estimation=True, all_layers=True,
+        dataset=nncf_amd.Dataset([x + i for i in range(subset)]), subset_size=subset,
+        advanced_parameters=nncf_amd.AdvancedCompressionParameters(
+            scale_estimation_params=nncf_amd.AdvancedScaleEstimationParameters(subset_size=se_subset)))
+    (scale,) = model._nncf_amd_se_scales.values()
+    assert tuple(scale.shape) == (16, 1, 1)
+    np.testing.assert_allclose(scale.cpu().numpy().reshape(-1), np.array(ref, np.float32), rtol=1e-5, atol=1e-8)

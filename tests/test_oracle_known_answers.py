@@ -180,3 +180,37 @@ def test_scale_estimation_literals(mode, init, steps, transpose_a, n_samples, re
         assert zp is None
     else:
         np.testing.assert_allclose(zp, np.array(ref_zp, np.float32).reshape(zp.shape), atol=1e-3, rtol=0)
+
+
+_PROCESS_STATS_CASES = [
+    # (reduced_shape, activation_shapes, subset_size, act_ch_axis | None, ref_s, ref_X)
+    ((2,), [(1, 2), (3, 2), (5, 2), (10, 2)], 2, None, [6, 7], np.array([6, 2, 7, 3]).reshape(2, 2)),
+    ((2,), [(2, 1), (2, 3), (2, 5), (2, 10)], 2, 0, [6, 7], np.array([6, 2, 7, 3]).reshape(2, 2)),
+    ((2,), [(5, 2), (5, 2)], 2, None, [2, 3], np.array([0, 2, 1, 3]).reshape(2, 2)),
+    ((2, 4), [(1, 2, 4), (3, 2, 4), (5, 2, 4), (10, 2, 4)], 2, None, np.arange(24, 32).reshape(2, 4),
+     np.array([24, 8, 25, 9, 26, 10, 27, 11, 28, 12, 29, 13, 30, 14, 31, 15]).reshape(2, 4, 2)),
+    ((2, 4), [(1, 100000, 2, 4), (3, 10000, 2, 4), (5, 1000, 2, 4), (10, 5, 2, 4)], 2, 1, np.arange(24, 32).reshape(2, 4),
+     np.array([24, 8, 25, 9, 26, 10, 27, 11, 28, 12, 29, 13, 30, 14, 31, 15]).reshape(2, 4, 2)),
+    ((2, 4), [(1, 2, 4), (1, 2, 4)], 2, None, np.arange(8, 16).reshape(2, 4),
+     np.array([0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13, 6, 14, 7, 15]).reshape(2, 4, 2)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(_PROCESS_STATS_CASES)))
+def test_process_stats_literals(case):
+    """The reference's known answers for process_stats (template_test_weights_compression.py:980-1054): which
+    calibration samples survive the subset sampling and the per-channel magnitudes; the oracle and the host mirror
+    (plain torch, runs on the CPU)."""
+    import torch
+
+    from nncf_amd.statistics import WCTensorStatistic, process_stats
+    reduced_shape, act_shapes, subset, axis, ref_s, ref_X = _PROCESS_STATS_CASES[case]
+    total = int(np.prod(reduced_shape))
+    means = [np.arange(i * total, (i + 1) * total, dtype=np.float32).reshape(reduced_shape) for i in range(len(act_shapes))]
+    kw = {} if axis is None else {"act_ch_axis": axis}
+    s, X = O.process_stats(means, act_shapes, subset, **kw)
+    assert s.shape == np.shape(ref_s) and X.shape == ref_X.shape
+    assert np.allclose(s, ref_s) and np.allclose(X, ref_X)
+    s_t, X_t = process_stats(WCTensorStatistic([torch.from_numpy(m) for m in means], list(act_shapes)), subset, **kw)
+    assert tuple(s_t.shape) == np.shape(ref_s) and tuple(X_t.shape) == ref_X.shape
+    assert np.allclose(s_t.numpy(), ref_s) and np.allclose(X_t.numpy(), ref_X)
