@@ -200,3 +200,15 @@ def test_c5_batched_full_size_vs_oracle(mode):
         assert np.array_equal(lut[codes], rc.ravel())
         if mode == "mxfp4":
             assert np.array_equal(np.ldexp(np.float32(1), host(cw.codebook).astype(np.int32).ravel() - 127), rs.ravel())
+
+
+@pytest.mark.parametrize("mode", ["mxfp4", "fp4"])
+@pytest.mark.parametrize("ident", ["neg", "pos", "neg-pos"])
+def test_reference_float_range_literals(mode, ident):
+    """tests/openvino/native/quantization/test_weights_compression.py:1510-1626 (the modes in scope) through the HIP
+    path: quantize + dequantize of the integer ramps, 1-D weight."""
+    from nncf_amd import weight_lowering as WL
+    from tests.test_oracle_known_answers import _RANGE_DATA, RANGE_REFS
+    w = np.array(_RANGE_DATA[ident], np.float32)
+    cw = WL.do_float_quantization(to_dev(w, "f32"), _cfg(mode, -1), -1)
+    assert np.allclose(host(WL.do_float_dequantization(cw)), np.array(RANGE_REFS[mode][ident], np.float32))

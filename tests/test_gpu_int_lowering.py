@@ -403,3 +403,39 @@ def test_batched_lowering_of_3d_moe_weights(mode, gs):
             codes = np.stack([p & 15, p >> 4], -1).ravel()
             lut = O.NF4_QUANTILES if mode == "nf4" else O.E2M1_VALUE_OF_CODE
             assert np.array_equal(lut[codes], rc.ravel())
+
+
+@pytest.mark.parametrize("ident", ["neg", "pos", "neg-pos"])
+def test_reference_int_range_literals(ident):
+    """tests/openvino/native/quantization/test_weights_compression.py:1489-1507 through the HIP path (1-D weight)."""
+    from tests.test_oracle_known_answers import _RANGE_DATA
+    w = np.array(_RANGE_DATA[ident], np.float32)
+    from nncf_amd import weight_lowering as WL
+    cw = WL.do_integer_quantization(to_dev(w, "f32"), _cfg("int4_sym", -1), -1)
+    assert np.allclose(np.abs(host(cw.tensor).astype(np.float32)), np.abs(w))
+
+
+@pytest.mark.parametrize("mode,pre_scale,pre_zp,raises", __import__("tests.test_oracle_known_answers", fromlist=["x"]).PRECOMPUTED_CASES)
+def test_reference_precomputed_parameter_cases(mode, pre_scale, pre_zp, raises):
+    """:1646-1688 through the HIP path: parameters come back verbatim, half a pair raises ValueError, and the codes
+    equal the oracle's wherever the quotient is a number (one precomputed scale is 0 under a zero weight: 0 / 0, whose
+    integer cast is undefined in the reference too, numpy warns about it)."""
+    from tests.test_oracle_known_answers import precomputed_inputs
+    from nncf_amd import weight_lowering as WL
+    weight, scale, zp = precomputed_inputs(pre_scale, pre_zp)
+    d = lambda a, k: None if a is None else torch.from_numpy(a).cuda()  # noqa: E731
+    if raises:
+        with pytest.raises(ValueError):
+            WL.do_integer_quantization(to_dev(weight, "f32"), _cfg(mode, -1), -1, d(scale, "f32"), d(zp, "i32"))
+        return
+    cw = WL.do_integer_quantization(to_dev(weight, "f32"), _cfg(mode, -1), -1, d(scale, "f32"), d(zp, "i32"))
+    ref_q, ref_s, ref_z = O.do_integer_quantization(weight, mode, -1, (-1,), scale, zp)
+    if pre_scale:
+        assert np.allclose(host(cw.scale), scale)
+    if mode.endswith("asym"):
+        if pre_zp:
+            assert np.allclose(host(cw.zero_point), zp)
+    else:
+        assert cw.zero_point is None
+    defined = np.ones(weight.shape, bool) if scale is None else scale != 0
+    assert np.array_equal(host(cw.tensor)[defined], ref_q[defined])

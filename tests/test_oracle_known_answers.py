@@ -214,3 +214,64 @@ def test_process_stats_literals(case):
     s_t, X_t = process_stats(WCTensorStatistic([torch.from_numpy(m) for m in means], list(act_shapes)), subset, **kw)
     assert tuple(s_t.shape) == np.shape(ref_s) and tuple(X_t.shape) == ref_X.shape
     assert np.allclose(s_t.numpy(), ref_s) and np.allclose(X_t.numpy(), ref_X)
+
+
+_RANGE_DATA = {"neg": [-8.0, -7.0, -6.0, -5.0, -4.0, -3.0, -2.0, -1.0, 0.0], "pos": [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0],
+               "neg-pos": [-8.0, -7.0, -6.0, -5.0, -4.0, -3.0, -2.0, -1.0, 0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0]}
+_FP4_RANGE_REF = {
+    "neg": [-8.0, -8.0, -5.333333492279053, -5.333333492279053, -4.0, -2.6666667461395264, -2.0, -1.3333333730697632, -0.0],
+    "pos": [-0.0, 1.3333333730697632, 2.0, 2.6666667461395264, 4.0, 5.333333492279053, 5.333333492279053, 8.0, 8.0],
+    "neg-pos": [-8.0, -8.0, -5.333333492279053, -5.333333492279053, -4.0, -2.6666667461395264, -2.0, -1.3333333730697632, -0.0,
+                1.3333333730697632, 2.0, 2.6666667461395264, 4.0, 5.333333492279053, 5.333333492279053, 8.0]}
+_MXFP4_RANGE_REF = {"neg": [-8.0, -8.0, -6.0, -4.0, -4.0, -3.0, -2.0, -1.0, -0.0], "pos": [-0.0, 1.0, 2.0, 3.0, 4.0, 4.0, 6.0, 8.0, 8.0],
+                    "neg-pos": [-8.0, -8.0, -6.0, -4.0, -4.0, -3.0, -2.0, -1.0, -0.0, 1.0, 2.0, 3.0, 4.0, 4.0, 6.0, 8.0]}
+RANGE_REFS = {"mxfp4": _MXFP4_RANGE_REF, "fp4": _FP4_RANGE_REF}
+
+
+@pytest.mark.parametrize("ident", ["neg", "pos", "neg-pos"])
+def test_int_compressed_weights_range(ident):
+    """tests/openvino/native/quantization/test_weights_compression.py:1489-1507: INT4_SYM codes of an integer ramp
+    equal the ramp in magnitude."""
+    w = np.array(_RANGE_DATA[ident], np.float32)
+    codes, _, _ = O.do_integer_quantization(w, "int4_sym", -1, (-1,))
+    assert np.allclose(np.abs(codes), np.abs(w))
+
+
+@pytest.mark.parametrize("mode", ["mxfp4", "fp4"])
+@pytest.mark.parametrize("ident", ["neg", "pos", "neg-pos"])
+def test_float_compressed_weights_range(mode, ident):
+    """:1510-1626 (TEST_FLOAT_COMPRESSED_REFS, the modes in scope): quantize + dequantize of the ramps."""
+    w = np.array(_RANGE_DATA[ident], np.float32)
+    values, scale = O.do_float_quantization(w, mode, -1, (-1,))
+    assert np.allclose(O.do_float_dequantization(values, scale), np.array(RANGE_REFS[mode][ident], np.float32))
+
+
+PRECOMPUTED_CASES = [("int8_asym", False, False, False), ("int8_asym", True, True, False), ("int8_asym", True, False, True),
+                     ("int8_asym", False, True, True), ("int4_asym", False, False, False), ("int4_asym", True, True, False),
+                     ("int4_asym", True, False, True), ("int4_asym", False, True, True), ("int8_sym", True, False, False),
+                     ("int8_sym", False, False, False), ("int4_sym", True, False, False), ("int4_sym", False, False, False)]
+
+
+def precomputed_inputs(pre_scale, pre_zp):
+    weight = ((np.arange(11) - 5) / 10).astype(np.float32)[:, None]
+    scale = -((np.arange(11) - 5) / 100).astype(np.float32)[:, None] if pre_scale else None
+    zp = np.arange(11).astype(np.int32)[:, None] if pre_zp else None
+    return weight, scale, zp
+
+
+@pytest.mark.parametrize("mode,pre_scale,pre_zp,raises", PRECOMPUTED_CASES)
+def test_int_quantization_with_precomputed_parameters(mode, pre_scale, pre_zp, raises):
+    """:1646-1688: given parameters come back verbatim (a zero scale among them included), half a pair raises."""
+    weight, scale, zp = precomputed_inputs(pre_scale, pre_zp)
+    if raises:
+        with pytest.raises(ValueError):
+            O.do_integer_quantization(weight, mode, -1, (-1,), scale, zp)
+        return
+    _, s, z = O.do_integer_quantization(weight, mode, -1, (-1,), scale, zp)
+    if pre_scale:
+        assert np.allclose(s, scale)
+    if mode.endswith("asym"):
+        if pre_zp:
+            assert np.allclose(z, zp)
+    else:
+        assert z is None
