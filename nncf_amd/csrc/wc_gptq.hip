@@ -60,24 +60,47 @@ __global__ __launch_bounds__(GTHR) void k_gptq_block(const float* __restrict__ w
         ev[k] = 0.0f;
     }
     typename Policy::Par par;
-    if (i1 % gs != 0) par = pol.load(a, r * ngroups + i1 / gs);  // the group began in an earlier block
+    // position of the sweep inside its quantization group, kept as counters: a 64-bit modulo per column would cost
+    // more than the column's whole dependent chain (no integer divider on the device)
+    int64_t gidx = r * ngroups + i1 / gs;
+    int64_t in_group = i1 % gs;
+    if (in_group != 0) par = pol.load(a, gidx);  // the group began in an earlier block
+    // the Hinv row of the NEXT column (its diagonal entry and this lane's 8 columns) is fetched from LDS while the
+    // current column is being quantized: two LDS round trips less in the per-column dependent chain
+    float hn[GCPL], hdn;
+    auto prefetch = [&](int i) {
+        const float* hr = hb + i * GB;
+        hdn = hr[i];
+#pragma unroll
+        for (int k = 0; k < GCPL; ++k) hn[k] = hr[k * GLPR + l];
+    };
+    prefetch(0);
 #pragma unroll
     for (int k0 = 0; k0 < GCPL; ++k0) {
         for (int lo = 0; lo < GLPR; ++lo) {
             const int i = k0 * GLPR + lo;
             if (i >= count) break;
-            const int64_t c = i1 + i;
-            if (c % gs == 0) {
+            if (in_group == 0) {
                 if (given) {  // parameters supplied by the caller (scale estimation inside GPTQ, gptq.py:319-327)
-                    par = pol.load(a, r * ngroups + c / gs);
+                    par = pol.load(a, gidx);
                 } else {
+                    const int64_t c = i1 + i;
                     typename Policy::Stat st = pol.stat_init();
                     for (int64_t k = l; k < gs; k += GLPR) pol.stat_add(st, wrow[c + k]);
                     pol.template stat_lanes<GLPR>(st);
                     par = pol.compute(st);
-                    if (active && l == 0) pol.template store<false>(a, r * ngroups + c / gs, par);
+                    if (active && l == 0) pol.template store<false>(a, gidx, par);
                 }
             }
+            if (++in_group == gs) {
+                in_group = 0;
+                ++gidx;
+            }
+            float hc[GCPL];
+#pragma unroll
+            for (int k = 0; k < GCPL; ++k) hc[k] = hn[k];
+            const float hd = hdn;
+            prefetch(i + 1 < GB ? i + 1 : GB - 1);
             // the owner (lane lo of the row) broadcasts column i
             const float wv = __builtin_bit_cast(
                 float, __builtin_amdgcn_ds_bpermute(((lane & ~(GLPR - 1)) + lo) * 4, __builtin_bit_cast(int, w[k0])));
@@ -85,19 +108,18 @@ __global__ __launch_bounds__(GTHR) void k_gptq_block(const float* __restrict__ w
             float val;
             pol.quant(wv, par, code, val);
             const float q = pol.dq(code, val, par);
-            const float* hrow = hb + i * GB;
-            const float err = (wv - q) / hrow[i];
+            const float err = (wv - q) / hd;
             if (l == lo) {
                 qv[k0] = q;
                 ev[k0] = err;
             }
             {
-                const float prod = err * hrow[k0 * GLPR + l];
+                const float prod = err * hc[k0];
                 w[k0] = l >= lo ? w[k0] - prod : w[k0];
             }
 #pragma unroll
             for (int k = k0 + 1; k < GCPL; ++k) {
-                const float prod = err * hrow[k * GLPR + l];
+                const float prod = err * hc[k];
                 w[k] = w[k] - prod;
             }
         }
