@@ -28,6 +28,31 @@ __global__ __launch_bounds__(256) void k_probe(const u4* __restrict__ in, uint32
         }
     }
 }
+// 2 : 1 mix (16 B in, 8 B out per lane): the traffic shape of the 8-bit lowering (bf16 in, one byte out)
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_probe_8bit(const u4* __restrict__ in, u2* __restrict__ out, int64_t nvec) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t step = (int64_t)gridDim.x * 256 * U;
+    for (int64_t base = wave_global * 64 * U; base < nvec; base += step) {
+        u4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = base + u * 64 + lane;
+            if (NT) r[u] = __builtin_nontemporal_load(&in[v < nvec ? v : nvec - 1]);
+            else r[u] = in[v < nvec ? v : nvec - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = base + u * 64 + lane;
+            u2 x;
+            x.x = r[u].x ^ r[u].y;
+            x.y = r[u].z ^ r[u].w;
+            if (v < nvec) { if (NT) __builtin_nontemporal_store(x, &out[v]); else out[v] = x; }
+        }
+    }
+}
 // lane owns 64 contiguous bytes via LDS-DMA staging; 16-byte output store per lane
 template <bool NT>
 __global__ __launch_bounds__(256) void k_probe_dma(const u4* __restrict__ in, u4* __restrict__ out, int64_t nvec) {
@@ -65,7 +90,7 @@ int main(int argc, char** argv) {
     const int NB = 16;
     std::vector<u4*> in(NB);
     std::vector<uint32_t*> out(NB);
-    for (int i = 0; i < NB; ++i) { CK(hipMalloc(&in[i], n * 2)); CK(hipMemset(in[i], i + 1, n * 2)); CK(hipMalloc(&out[i], n / 2)); }
+    for (int i = 0; i < NB; ++i) { CK(hipMalloc(&in[i], n * 2)); CK(hipMemset(in[i], i + 1, n * 2)); CK(hipMalloc(&out[i], n)); }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int64_t nvec = n / 8;
@@ -87,6 +112,20 @@ int main(int argc, char** argv) {
         timeit("U8 plain", [&](int i) { hipLaunchKernelGGL((k_probe<8, false, false>), dim3(grid), dim3(256), 0, st, in[i], out[i], nvec); });
         timeit("U8 nt-both", [&](int i) { hipLaunchKernelGGL((k_probe<8, true, true>), dim3(grid), dim3(256), 0, st, in[i], out[i], nvec); });
         timeit("U2 plain", [&](int i) { hipLaunchKernelGGL((k_probe<2, false, false>), dim3(grid), dim3(256), 0, st, in[i], out[i], nvec); });
+        {
+            auto timeit8 = [&](const char* name, auto launch) {
+                for (int i = 0; i < NB; ++i) launch(i);
+                CK(hipEventRecord(e0, st));
+                for (int r = 0; r < 5; ++r) for (int i = 0; i < NB; ++i) launch(i);
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                double us = ms * 1e3 / (5 * NB);
+                printf("%-40s %.2f us/tensor  %.1f GB/s (in+out, 2:1)\n", name, us, n * 3.0 / us * 1e-3);
+            };
+            timeit8("8-bit mix U4 plain", [&](int i) { hipLaunchKernelGGL((k_probe_8bit<4, false>), dim3(grid), dim3(256), 0, st, in[i], (u2*)out[i], nvec); });
+            timeit8("8-bit mix U4 nt", [&](int i) { hipLaunchKernelGGL((k_probe_8bit<4, true>), dim3(grid), dim3(256), 0, st, in[i], (u2*)out[i], nvec); });
+            timeit8("8-bit mix U8 nt", [&](int i) { hipLaunchKernelGGL((k_probe_8bit<8, true>), dim3(grid), dim3(256), 0, st, in[i], (u2*)out[i], nvec); });
+        }
         timeit("DMA plain", [&](int i) { hipLaunchKernelGGL((k_probe_dma<false>), dim3(grid), dim3(256), 0, st, in[i], (u4*)out[i], nvec); });
         timeit("DMA nt", [&](int i) { hipLaunchKernelGGL((k_probe_dma<true>), dim3(grid), dim3(256), 0, st, in[i], (u4*)out[i], nvec); });
     }
