@@ -350,6 +350,22 @@ int nncf_amd_cholinv_block(const float* a, int64_t lda, float* linv, int64_t ldo
 int nncf_amd_decompress(const uint8_t* codes, int mode, int64_t n_groups, int64_t group_size, const void* scale,
                         int scale_kind, const uint8_t* zero_point, void* out, int out_dtype, void* stream);
 
+/*
+ * Export of per-channel INT8 weights to the GPTQ v2 tensor layout (optional export).
+ * Replaces the tensor work of convert_linear_module (src/nncf/experimental/torch/gptqmodel/convertor.py:35-84):
+ * decompress + gptqmodel's TritonV2QuantLinear.pack on the CPU (bits = 8, group_size = -1, desc_act = False).
+ *   codes   : [out_features, in_features] uint8 (codes_signed = 0) or int8 (1: stored as code + 128, zero point 128)
+ *   qweight : [in_features / 4, out_features] int32, byte j of word (i, o) = code of weight[o, 4 i + j]
+ * qzeros [1, out_features / 4] int32 is the byte image of the uint8 zero points, scales [1, out_features] fp16 the
+ * scale vector: both are views on the host side.  in_features and out_features must be multiples of 4.
+ */
+int nncf_amd_gptq_pack8(const void* codes, int codes_signed, int64_t out_features, int64_t in_features,
+                        int32_t* qweight, void* stream);
+/* The forward of that layout: weight[o, k] = RN_fp16((byte k of column o - zero[o]) * scale[o]) cast to out_dtype,
+ * [out_features, in_features]; replaces the dequantization inside TritonV2QuantLinear.forward. */
+int nncf_amd_gptq_dequant8(const int32_t* qweight, const int32_t* qzeros, const void* scales, int64_t in_features,
+                           int64_t out_features, void* weight, int out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,8 @@ SIGNATURES = {
     "nncf_amd_gptq_block": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "nncf_amd_cholinv_block": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "nncf_amd_gptq_pack8": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "nncf_amd_gptq_dequant8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

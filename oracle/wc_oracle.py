@@ -705,3 +705,46 @@ def gptq_quantize_weights(hessian, weight, mode, group_size, inputs=None, damp_p
     else:
         zps = None
     return Q.astype(np.float32), scales, zps
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPTQ v2 tensor layout of a per-channel INT8 weight (test infrastructure, like everything in this file).
+# The reference hands this to a third-party package that is absent here (gptqmodel==2.2.0,
+# tests/integration/gptq_model/requirements_extra.txt; call site src/nncf/experimental/torch/gptqmodel/
+# convertor.py:69-82).  Restated from that package's published `pack`: integer codes re-derived from the decompressed
+# weight column by column, then OR-ed into 32-bit words along the input axis.  PARITY UNPINNED for the layout: the
+# reference holds no packed tensors; its own test (tests/integration/gptq_model/test_converter.py:25-57) checks that
+# the converted layer computes the same linear, which `gptq_dequant8_ref` lets the tests check too.
+def gptq_pack8_ref(weight, scale, zero):
+    """weight [out, in] decompressed values, scale / zero [out] -> (qweight [in / 4, out] int32, qzeros [1, out / 4]
+    int32): intweight[i, o] = round((W[o, i] + zero[o] * scale[o]) / scale[o]), 4 codes per word, low byte first."""
+    w = np.asarray(weight, dtype=np.float32)
+    s = np.asarray(scale, dtype=np.float16).astype(np.float32).reshape(-1)
+    z = np.asarray(zero, dtype=np.float32).reshape(-1)
+    out_f, in_f = w.shape
+    intweight = np.empty((in_f, out_f), dtype=np.uint32)
+    for idx in range(in_f):
+        intweight[idx] = np.round((w[:, idx] + z * s) / s).astype(np.int64).astype(np.uint32)
+    qweight = np.zeros((in_f // 4, out_f), dtype=np.uint32)
+    for row in range(in_f // 4):
+        for j in range(4):
+            qweight[row] |= intweight[row * 4 + j] << np.uint32(8 * j)
+    zi = z.astype(np.uint32)
+    qzeros = np.zeros((1, out_f // 4), dtype=np.uint32)
+    for col in range(out_f // 4):
+        for j in range(4):
+            qzeros[0, col] |= zi[col * 4 + j] << np.uint32(8 * j)
+    return qweight.view(np.int32), qzeros.view(np.int32)
+
+
+def gptq_dequant8_ref(qweight, qzeros, scales):
+    """The dequantization of that layout in fp16 arithmetic: W[o, 4 i + j] = (byte j of qweight[i, o] - zero[o]) *
+    scale[o] -> [out, in] fp16."""
+    qw = np.asarray(qweight).view(np.uint32)
+    in4, out_f = qw.shape
+    z = np.asarray(qzeros).view(np.uint32).reshape(-1)
+    zeros = np.stack([(z >> np.uint32(8 * j)) & np.uint32(255) for j in range(4)], axis=1).reshape(-1)[:out_f]
+    codes = np.stack([(qw >> np.uint32(8 * j)) & np.uint32(255) for j in range(4)], axis=1).reshape(in4 * 4, out_f)
+    d = (codes.astype(np.int32) - zeros.astype(np.int32)[None, :]).astype(np.float16)
+    s = np.asarray(scales, dtype=np.float16).reshape(1, -1)
+    return (d * s).astype(np.float16).T.copy()
