@@ -248,8 +248,8 @@ def main():
         total_in_bytes = 2 * model_elems if strong else job.in_bytes * world
         value = total_in_bytes / (elapsed / args.steps) / 1e9
         achieved = job.alg_bytes / (dev_ms_per_step * 1e-3) / 1e9  # rank 0's shard on rank 0's GPU
-        if gs != -1:  # grouped modes: multi-tensor tile kernel, launches of <= 48 tensors
-            launches = -(-job.n // 48)
+        if gs != -1:  # grouped modes: multi-tensor tile kernel, launches of <= MAX_BATCH tensors
+            launches = -(-job.n // job._lib.MAX_BATCH)
             kernel = "wc::k_grouped_batch<%s, bf16, VPG=%d>" % (
                 {"int4_sym": "IntPolicyT<INT4_SYM>", "int4_asym": "IntPolicyT<INT4_ASYM>", "nf4": "FloatPolicy<NF4>",
                  "mxfp4": "FloatPolicy<E2M1, MXFP4>"}.get(mode, mode), gs * 2 // 16)
@@ -257,7 +257,7 @@ def main():
             per_class = {}
             for w in job.weights:
                 per_class[w.shape[1]] = per_class.get(w.shape[1], 0) + 1
-            launches = sum(-(-c // 48) for c in per_class.values())
+            launches = sum(-(-c // job._lib.MAX_BATCH) for c in per_class.values())
             kernel = "wc::k_rows_batch<IntPolicyT<%s>, bf16> (%d row-length classes)" % (mode.upper(), len(per_class))
         # HBM bytes per launch: NOT measured by this run.  The figure is read from the committed rocprofv3 --pmc passes
         # of this same command (profiles/r2_traffic.json, made by tools/traffic_from_pmc.py) and labelled as such;

@@ -218,7 +218,10 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
 // below the HBM rate.  Tensors are cut into the same 64*VPL-vector tiles; tile ids run through all tensors of the
 // batch (tile_start = prefix sums) and the resident waves stride over them, prefetching their next tile by LDS-DMA
 // while they work on the current one.  Always "lean": packed codes + computed parameters only.
-constexpr int kMaxBatch = 48;
+#ifndef WC_ABL
+#define WC_ABL 0  // developer builds: bit 0 no parameter stores, 1 no code stores, 2 no loads, 3 no arithmetic
+#endif
+constexpr int kMaxBatch = 80;  // sizeof(BatchArgs) must stay under the 4 KiB of kernel arguments
 #ifndef WC_GROUPS
 #define WC_GROUPS 32
 #endif
@@ -241,9 +244,11 @@ struct BatchArgs {
     uint32_t* done;                 // per part: teams that have made their failing claim (same stride), zero at launch
     uint32_t log2_groups;           // claim groups of this launch = 1 << log2_groups (<= grid)
     uint32_t chunk;                 // tiles per claim (k_grouped_batch; 1 for the row kernels' units)
-    uint32_t teams_on[kClaimGroups];  // teams (waves or blocks) that serve each part
-    uint32_t part_lo[kClaimGroups + 1];  // tile range of each part (proportional to the blocks serving it)
+    uint32_t teams_on[kClaimGroupsUsed];  // teams (waves or blocks) that serve each part
+    uint32_t part_lo[kClaimGroupsUsed + 1];  // tile range of each part (proportional to the blocks serving it)
 };
+static_assert(kClaimGroupsUsed <= kClaimGroups, "parts of a launch <= counters of a slot");
+static_assert(sizeof(BatchArgs) <= 4096, "BatchArgs is passed by value as the kernel argument");
 // Tile claim counters.  Waves make unequal progress (the hardware favours the oldest waves: with a static stride
 // the first blocks finish in half the time of the last ones and the launch ends in a long under-occupied tail), so
 // tiles are claimed: the tile range is cut into 2^k contiguous parts, block x serves part (x / 8) mod 2^k (eight
@@ -276,13 +281,22 @@ static inline uint32_t batch_set(BatchArgs& b, int j, uint32_t acc, int64_t nvec
 // one 16-byte-per-lane LDS-DMA load, non-temporal: global (SGPR base + 32-bit VGPR offset) -> LDS (M0 + lane*16).
 // Written out so that the issue path holds no VALU instruction at all (a VALU op there queues behind the other
 // waves' arithmetic and delays the load by up to a whole compute phase).
-// returning atomic add of 1 on a wave-uniform address, issued by the calling lanes; the caller waits (vmcnt).
-// Inline so that the compiler neither aggregates it across the wave nor waits for the result on the spot.
-__device__ __forceinline__ uint32_t claim_async(uint32_t* ctr) {
-    uint32_t old;
-    const uint32_t zero = 0, one = 1;
-    asm volatile("global_atomic_add %0, %1, %2, %3 sc0 sc1" : "=v"(old) : "v"(zero), "v"(one), "s"(ctr) : "memory");  // sc0: return, sc1: agent scope
-    return old;
+// Returning atomic add of 1 on a wave-uniform address, issued by the calling lanes; the result arrives later, behind
+// a vmcnt wait of the caller's choosing.  It arrives in the accumulation register a0 (a1 holds the addend), NOT in a
+// register the compiler allocates: an asm output that is written asynchronously can be copied by the compiler
+// before the data is there and copied back over it afterwards (seen in a loop with two call sites: every claim of a
+// wave was read as the first one).  The compiler does not touch a0 / a1 in these kernels (no MFMA, no spills: the
+// AGPR count of every instantiation is 2, checked at build time by tools/check_kernel_regs.py).
+__device__ __forceinline__ void claim_init() { asm volatile("v_accvgpr_write_b32 a1, 1" ::: "a1"); }
+__device__ __forceinline__ void claim_async(uint32_t* ctr) {
+    const uint32_t zero = 0;
+    asm volatile("global_atomic_add a0, %0, a1, %1 sc0 sc1" : : "v"(zero), "s"(ctr) : "memory", "a0");  // sc0: return, sc1: agent scope
+}
+// the value of the claim issued last by this lane; valid after a vmcnt wait that covers it
+__device__ __forceinline__ uint32_t claim_value() {
+    uint32_t v;
+    asm volatile("v_accvgpr_read_b32 %0, a0" : "=v"(v) : : "memory", "a0");
+    return v;
 }
 // Called by ONE lane of a team after its failing claim has RETURNED (so the claim was performed before this add is
 // issued): the last team of the part puts the part's two counters back to zero for the next launch.
@@ -300,15 +314,23 @@ __device__ __forceinline__ void dma16_nt(const char* sbase, uint32_t voff, uint3
                  : "memory", "m0");
 }
 
-// Per-wave schedule (one tile = 64*VPL vectors in flight per wave, processed from registers):
-//     wait DMA(t) -> LDS image to registers -> issue DMA(t + stride) -> store packed codes of the PREVIOUS tile
-//     -> statistics, parameters, parameter store -> quantize + pack (kept in registers until the next round)
-// The deferred store keeps the s_waitcnt vmcnt(0) at the top from waiting on a store that was issued a moment
-// ago (vmcnt counts stores too); the tensor descriptors of the current and the next tile stay in SGPRs and are
-// reloaded from the kernel arguments only when a wave crosses into another tensor.
+// Per-wave schedule: TWO tiles of 64*VPL vectors in flight per wave (two wave-private LDS images), the current tile
+// processed from registers:
+//     wait DMA(t) [DMA(t+1) stays in flight] -> LDS image to registers -> store the PREVIOUS tile's packed codes and
+//     group parameters -> (claim) -> issue DMA(t+2) into the image just read -> statistics, parameters, quantize +
+//     pack (kept in registers until the next round)
+// Why two images: a wave that finds its tile landed still needs issue slots for the four LDS reads and the DMA of
+// its next tile, and the SIMD hands those out oldest wave first -- behind the arithmetic of the other waves the
+// turn-round of a single image took up to a whole compute phase, during which the wave had nothing in flight.
+// Every output store of a tile is deferred to the next round and placed BEFORE the DMA issue, so the youngest
+// VPL vector-memory operations at the top of the loop are exactly DMA(t+1): `s_waitcnt vmcnt(VPL)` waits for
+// DMA(t), the claim and the stores but not for the tile behind (vmcnt counts loads, stores and atomics in issue
+// order).  The tensor descriptors of the three tiles stay in SGPRs and are reloaded from the kernel arguments only
+// when a wave crosses into another tensor.
 template <typename Policy, int DT, int VPG>
 __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     constexpr int VPL = kVPL;
+    static_assert(VPL == 4, "the loop's s_waitcnt vmcnt(4) is the number of DMA instructions per tile");
     constexpr int E = Elem<DT>::kPerVec;
     constexpr int NE = VPL * E;
     constexpr int GPL = VPG >= VPL ? 1 : VPL / VPG;
@@ -316,7 +338,7 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     constexpr int SG = NE / GPL;
     constexpr int TILE = 64 * VPL;
     constexpr int NW = NE / 8;  // packed dwords per lane
-    __shared__ Vec16 stage[4][TILE];
+    __shared__ Vec16 stage[4][2][TILE];
     __shared__ __align__(16) float lds[kPolicyLds];
     Policy::init_shared(lds);
     __syncthreads();
@@ -325,8 +347,7 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     const Policy pol(o, lds);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    Vec16* my = stage[wave];
-    const uint32_t lds_base = (uint32_t)(uintptr_t)my;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)stage[wave];
     uint32_t src_off[VPL];
 #pragma unroll
     for (int u = 0; u < VPL; ++u) {
@@ -353,16 +374,17 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
         d.aux = b.aux[i];
         return d;
     };
-    auto issue_dma = [&](uint32_t t, const Desc& d) {
+    auto issue_dma = [&](uint32_t t, const Desc& d, int q) {
         const uint32_t lt = t - d.start;  // tile inside the tensor
         const char* tbase = d.w + (uint64_t)lt * (TILE * 16);
+        const uint32_t image = lds_base + (uint32_t)q * (TILE * 16);
         if (lt < d.nfull) {
 #pragma unroll
-            for (int u = 0; u < VPL; ++u) dma16_nt(tbase, src_off[u], lds_base + u * 1024);
+            for (int u = 0; u < VPL; ++u) dma16_nt(tbase, src_off[u], image + u * 1024);
         } else {
             const uint32_t last = (d.rem - 1) * 16u;  // partial tile: clamp to the last valid vector
 #pragma unroll
-            for (int u = 0; u < VPL; ++u) dma16_nt(tbase, src_off[u] < last ? src_off[u] : last, lds_base + u * 1024);
+            for (int u = 0; u < VPL; ++u) dma16_nt(tbase, src_off[u] < last ? src_off[u] : last, image + u * 1024);
         }
     };
     auto store_packed = [&](uint8_t* dst, const uint32_t* w) {
@@ -377,89 +399,252 @@ __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
     uint32_t* done = b.done + part * kClaimStride;
     // a claim hands out `chunk` consecutive tiles: claimed value v -> tiles lo + v * chunk ...
     const uint32_t chunk = b.chunk;
-    uint32_t claim = 0;
-    if (lane == 0) claim = claim_async(ctr);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
-    uint32_t t = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim) * chunk;
-    if (t >= hi) {  // (a wave makes exactly one failing claim, the last thing it does with the counter)
+    claim_init();
+    // The wave's tile sequence, in prefetch order.  `claim` is always in flight while a chunk is being handed out;
+    // the caller makes sure it has landed (a vmcnt wait that covers it) before a call that may start a new chunk.
+    // A wave makes exactly one failing claim, the last thing it does with the counter.
+    uint32_t nxt = 0, nxt_end = 0;  // next tile to hand out, end of its chunk
+    bool more = true;
+    auto next_tile = [&]() -> uint32_t {  // hi: no more tiles
+        if (nxt < nxt_end) return nxt++;
+        if (!more) return hi;
+        const uint32_t c = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_value()) * chunk;
+        if (c >= hi) {
+            more = false;
+            return hi;
+        }
+        nxt_end = c + chunk < hi ? c + chunk : hi;
+        nxt = c + 1;
+        if (lane == 0) claim_async(ctr);
+        return c;
+    };
+    if (lane == 0) claim_async(ctr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t t = next_tile();
+    if (t >= hi) {
         if (lane == 0) claim_done(ctr, done, b.teams_on[part]);
         return;
     }
-    uint32_t cend = t + chunk < hi ? t + chunk : hi;  // end of the chunk being worked on
 #ifdef WC_CLK  // developer build: per-wave start/end times into scale[0] (read back by tools/kbench.hip, WC_CLK=<file>)
     const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t ph[4] = {0, 0, 0, 0}, ntile = 0;  // cycles in: top wait, LDS read, stores + DMA issue, arithmetic
+#define WC_STAMP(k) { const uint64_t now_ = __builtin_readcyclecounter(); ph[k] += now_ - last_; last_ = now_; }
+#else
+#define WC_STAMP(k)
 #endif
     int i = 0;
     while (t >= b.tile_start[i + 1]) ++i;
     Desc cur = load_desc(i);
-    issue_dma(t, cur);
-    // claim of the chunk after this one: in flight together with the DMA, both waited for at the loop top
-    if (lane == 0) claim = claim_async(ctr);
+    issue_dma(t, cur, 0);
+    if (nxt >= nxt_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (one-tile chunks)
+    uint32_t t1 = next_tile();
+    Desc d1 = cur;
+    if (t1 < hi) {
+        if (t1 >= d1.end) {
+            do ++i; while (t1 >= b.tile_start[i + 1]);
+            d1 = load_desc(i);
+        }
+        issue_dma(t1, d1, 1);
+    }
+    int q = 0;  // image of the current tile
+    uint32_t round = 0;
+    // outputs of the previous tile, stored at the start of the next round
     uint32_t pend[NW];
     uint8_t* pend_dst = nullptr;  // per lane; NULL = nothing pending
+    typename Policy::Par pend_par[GPL];
+    uint32_t pend_g0 = 0;
+    bool pend_lead = false;  // this lane stores the parameters of its groups
+    GroupArgs po = o;        // the previous tile's parameter outputs
     for (;;) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
+#ifdef WC_CLK
+        uint64_t last_ = __builtin_readcyclecounter();
+        ++ntile;
+#endif
+#if WC_ABL & 4
+        // (no loads to wait for; the stores are left in flight)
+#else
+        // DMA(t) is followed by: the stores of its own round (>= 1 instruction from round 1 on), DMA(t+1) (4) and
+        // the stores of the round after (>= 1).  From round 3 on at least 6 younger operations exist; all but the 5
+        // youngest are waited for, which also covers a claim issued in the last round (it sits before that round's DMA).
+        if (t1 >= hi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (round >= 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
+        WC_STAMP(0)
         float f[NE];
+        {
+            const Vec16* img = stage[wave][q];
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) {
-            const Vec16 raw = my[lane * VPL + (k ^ rot)];
-            unpack<DT>(raw, f + k * E);
+            for (int k = 0; k < VPL; ++k) {
+                const Vec16 raw = img[lane * VPL + (k ^ rot)];
+                unpack<DT>(raw, f + k * E);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        uint32_t tn = t + 1;
-        const bool new_chunk = tn >= cend;  // wave-uniform
-        if (new_chunk) tn = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim) * chunk;
-        Desc nxt = cur;
-        if (tn < hi) {
-            if (tn >= nxt.end) {
-                do ++i; while (tn >= b.tile_start[i + 1]);
-                nxt = load_desc(i);
-            }
-            issue_dma(tn, nxt);
-            if (new_chunk) {
-                cend = tn + chunk < hi ? tn + chunk : hi;
-                if (lane == 0) claim = claim_async(ctr);
+        WC_STAMP(1)
+        uint32_t t2 = hi;
+        Desc d2 = d1;
+        if (t1 < hi) {
+            t2 = next_tile();
+            if (t2 < hi) {
+                if (t2 >= d2.end) {
+                    do ++i; while (t2 >= b.tile_start[i + 1]);
+                    d2 = load_desc(i);
+                }
+#if !(WC_ABL & 4)
+                issue_dma(t2, d2, q);
+#endif
             }
         }
+        asm volatile("" ::: "memory");  // the stores below stay younger than the DMA above
+#if !(WC_ABL & 2)
         if (pend_dst) store_packed(pend_dst, pend);
+#endif
+#if !(WC_ABL & 1)
+        if (pend_lead) {
+#pragma unroll
+            for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(po, pend_g0 + gi, pend_par[gi]);
+        }
+#endif
+        WC_STAMP(2)
         const uint32_t lt = t - cur.start;
-        o.scale_out = cur.scale;
-        o.zp_out = (int32_t*)cur.aux;
-        o.e8m0_out = (uint8_t*)cur.aux;
         const uint32_t in_tile = lt < cur.nfull ? (uint32_t)TILE : cur.rem;
         const bool live = (uint32_t)(lane * VPL) < in_tile;  // rem % VPL == 0 (host): a lane is all live or all dead
         const uint32_t v0 = lt * TILE + lane * VPL;          // first vector of this lane, < 2^30
-        const uint32_t g0 = v0 / VPG;
-        typename Policy::Par par[GPL];
+#if WC_ABL & 8
+#pragma unroll
+        for (int j = 0; j < NW; ++j) pend[j] = __float_as_uint(f[j] + f[j + NW]);
+#else
 #pragma unroll
         for (int gi = 0; gi < GPL; ++gi) {
             typename Policy::Stat st = pol.stat_init();
             pol.template stat_add_vec<SG>(st, f + gi * SG);
             if constexpr (LPG > 1) pol.template stat_lanes<LPG>(st);
-            par[gi] = pol.compute(st);
+            pend_par[gi] = pol.compute(st);
         }
-        if (live && (lane & (LPG - 1)) == 0) {
-#pragma unroll
-            for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(o, g0 + gi, par[gi]);
-        }
-        pol.template pack_lane<NE, GPL>(par, f, pend);
+        pol.template pack_lane<NE, GPL>(pend_par, f, pend);
+#endif
         pend_dst = live ? cur.packed + (uint64_t)v0 * (E / 2) : nullptr;
-        if (tn >= hi) break;
-        t = tn;
-        cur = nxt;
+        pend_lead = live && (lane & (LPG - 1)) == 0;
+        pend_g0 = v0 / VPG;
+        po.scale_out = cur.scale;
+        po.zp_out = (int32_t*)cur.aux;
+        po.e8m0_out = (uint8_t*)cur.aux;
+#ifdef WC_CLK
+        asm volatile("" : "+v"(pend[0]));
+#endif
+        WC_STAMP(3)
+        if (t1 >= hi) break;
+        t = t1;
+        cur = d1;
+        t1 = t2;
+        d1 = d2;
+        q ^= 1;
+        ++round;
     }
     if (pend_dst) store_packed(pend_dst, pend);
-    if (lane == 0) claim_done(ctr, done, b.teams_on[part]);  // the claim consumed last was the failing one
+    if (pend_lead) {
+#pragma unroll
+        for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(po, pend_g0 + gi, pend_par[gi]);
+    }
+    // every claim issued has been consumed: the one consumed last was the failing one, and it has returned
+    if (lane == 0) claim_done(ctr, done, b.teams_on[part]);
 #ifdef WC_CLK
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & 63) == 0) {
-        uint64_t* rec = (uint64_t*)b.scale[0] + (size_t)(blockIdx.x * 4 + wave) * 4;
+        uint64_t* rec = (uint64_t*)b.scale[0] + (size_t)(blockIdx.x * 4 + wave) * 8;
         rec[0] = rt0;
         rec[1] = __builtin_amdgcn_s_memrealtime();
         rec[2] = __builtin_readcyclecounter() - clk0;
-        rec[3] = 0;
+        rec[3] = ntile;
+        rec[4] = ph[0];
+        rec[5] = ph[1];
+        rec[6] = ph[2];
+        rec[7] = ph[3];
     }
 #endif
+}
+
+// One tile per wave, one launch-wide grid of tiles/4 blocks: the hardware's workgroup dispatcher hands out the tiles
+// (in address order), occupancy hides the load latency.  Experimental alternative to the persistent claimed kernel
+// above (NNCF_AMD_TILE_ONCE=1).
+template <typename Policy, int DT, int VPG>
+__global__ __launch_bounds__(256) void k_grouped_once(BatchArgs b) {
+    constexpr int VPL = kVPL;
+    constexpr int E = Elem<DT>::kPerVec;
+    constexpr int NE = VPL * E;
+    constexpr int GPL = VPG >= VPL ? 1 : VPL / VPG;
+    constexpr int LPG = VPG >= VPL ? VPG / VPL : 1;
+    constexpr int SG = NE / GPL;
+    constexpr int TILE = 64 * VPL;
+    constexpr int NW = NE / 8;
+    __shared__ Vec16 stage[4][TILE];
+    __shared__ __align__(16) float lds[kPolicyLds];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t t = blockIdx.x * 4 + wave;
+    const uint32_t total = b.tile_start[b.n];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)stage[wave];
+    // tensor of this tile: binary search over the prefix sums (wave-uniform, scalar loads)
+    int lo_i = 0, hi_i = b.n;
+    if (t < total) {
+        while (hi_i - lo_i > 1) {
+            const int mid = (lo_i + hi_i) >> 1;
+            if (t >= b.tile_start[mid]) lo_i = mid;
+            else hi_i = mid;
+        }
+        const uint32_t lt = t - b.tile_start[lo_i];
+        const char* tbase = (const char*)b.w[lo_i] + (uint64_t)lt * (TILE * 16);
+        const uint32_t nfull = b.nfull[lo_i];
+        const uint32_t last = lt < nfull ? 0xffffffffu : (b.rem[lo_i] - 1) * 16u;
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) {
+            const int sidx = u * 64 + lane;
+            const uint32_t off = (uint32_t)((sidx & ~3) + ((sidx & 3) ^ ((sidx >> 4) & 3))) * 16u;
+            dma16_nt(tbase, off < last ? off : last, lds_base + u * 1024);
+        }
+    }
+    Policy::init_shared(lds);
+    __syncthreads();
+    if (t >= total) return;
+    GroupArgs o = {};
+    o.mode = b.mode;
+    const Policy pol(o, lds);
+    const int rot = (lane >> 2) & 3;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float f[NE];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        const Vec16 raw = stage[wave][lane * VPL + (k ^ rot)];
+        unpack<DT>(raw, f + k * E);
+    }
+    const uint32_t lt = t - b.tile_start[lo_i];
+    const uint32_t in_tile = lt < b.nfull[lo_i] ? (uint32_t)TILE : b.rem[lo_i];
+    const bool live = (uint32_t)(lane * VPL) < in_tile;
+    const uint32_t v0 = lt * TILE + lane * VPL;
+    typename Policy::Par par[GPL];
+#pragma unroll
+    for (int gi = 0; gi < GPL; ++gi) {
+        typename Policy::Stat st = pol.stat_init();
+        pol.template stat_add_vec<SG>(st, f + gi * SG);
+        if constexpr (LPG > 1) pol.template stat_lanes<LPG>(st);
+        par[gi] = pol.compute(st);
+    }
+    uint32_t out[NW];
+    pol.template pack_lane<NE, GPL>(par, f, out);
+    if (live) {
+        uint8_t* dst = b.packed[lo_i] + (uint64_t)v0 * (E / 2);
+        if constexpr (NW == 1) st<true>((uint32_t*)dst, out[0]);
+        if constexpr (NW == 2) st<true>((u32x2*)dst, u32x2{out[0], out[1]});
+        if constexpr (NW == 4) st<true>((u32x4*)dst, u32x4{out[0], out[1], out[2], out[3]});
+        if ((lane & (LPG - 1)) == 0) {
+            o.scale_out = b.scale[lo_i];
+            o.zp_out = (int32_t*)b.aux[lo_i];
+            o.e8m0_out = (uint8_t*)b.aux[lo_i];
+#pragma unroll
+            for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(o, v0 / VPG + gi, par[gi]);
+        }
+    }
 }
 
 // blocks of `kernel` the device holds at once (cached by the caller per kernel instantiation)
@@ -481,6 +666,7 @@ static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block,
                                  uint32_t chunk = 1, int groups_used = kClaimGroupsUsed) {
     const uint32_t units = b.tile_start[b.n];
     if (blocks < 1) return hipSuccess;
+    if (groups_used > kClaimGroupsUsed) groups_used = kClaimGroupsUsed;  // BatchArgs holds that many parts
     int lg = 0;
     while ((16 << lg) <= blocks && (2 << lg) <= groups_used) ++lg;  // at least one octet of blocks per part
     const int groups = 1 << lg;
@@ -521,10 +707,15 @@ static hipError_t launch_batch_kernel(BatchArgs& b, hipStream_t s) {
     static const int resident = resident_blocks(k_grouped_batch<Policy, DT, VPG>, per_cu);
     static const uint32_t chunk = (uint32_t)tile_knob("NNCF_AMD_CLAIM_CHUNK", 1, 64, kClaimChunk);
     static const int groups = [] {
-        const int v = tile_knob("NNCF_AMD_CLAIM_GROUPS", 1, kClaimGroups, kTileClaimGroups);
+        const int v = tile_knob("NNCF_AMD_CLAIM_GROUPS", 1, kClaimGroupsUsed, kTileClaimGroups);
         return (v & (v - 1)) == 0 ? v : kTileClaimGroups;
     }();
     const int64_t blocks = ((int64_t)b.tile_start[b.n] + 3) / 4;
+    static const int once = tile_knob("NNCF_AMD_TILE_ONCE", 0, 1, 0);
+    if (once) {
+        hipLaunchKernelGGL((k_grouped_once<Policy, DT, VPG>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+        return hipPeekAtLastError();
+    }
     return launch_claimed(k_grouped_batch<Policy, DT, VPG>, (int)(blocks < resident ? blocks : resident), 4, b, s, chunk,
                           groups);
 }

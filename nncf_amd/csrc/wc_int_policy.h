@@ -66,11 +66,20 @@ struct IntPolicyT {
         s.lo = block_allreduce<4>(s.lo, OpMin(), smem);
         s.hi = block_allreduce<4>(s.hi, OpMax(), smem + 8);
     }
+    // r = RN(1/scale), correctly rounded (quant_n_div depends on it): v_rcp_f32 + one Newton step lands on RN(1/s) or
+    // on the float next to it; the residual e = 1 - s*r is exactly representable then (|e| < 2^-23, a multiple of
+    // 2^-47 relative to s*r ~ 1), and r is the nearest float iff |1/s - r| = |e| / |s| <= ulp(r) / 2, an exact
+    // comparison (the right side is |s| times a power of two).  Otherwise the nearest float is one step further in
+    // the direction of sign(e) (in magnitude: |1/s| - |r| = e / |s|).
     __device__ __forceinline__ void finish(Par& p) const {
         const float r0 = __builtin_amdgcn_rcpf(p.scale);
-        p.r = fmaf(fmaf(-p.scale, r0, 1.0f), r0, r0);
+        float r = fmaf(fmaf(-p.scale, r0, 1.0f), r0, r0);
+        const float e = fmaf(-p.scale, r, 1.0f);
+        const float half_ulp_s = ldexpf(fabsf(p.scale), __builtin_amdgcn_frexp_expf(r) - 25);
+        if (fabsf(e) > half_ulp_s) r = __builtin_bit_cast(float, __builtin_bit_cast(int, r) + (e > 0.0f ? 1 : -1));
+        p.r = r;
         const float as = fabsf(p.scale);
-        p.fast = (as >= 7.888609052210118e-31f) && (as <= 1.2676506002282294e+30f);  // [2^-100, 2^100]
+        p.fast = (as >= 8.673617379884035e-19f) && (as <= 1.152921504606847e+18f);  // [2^-60, 2^60]: no under/overflow below
         if (!(fabsf(p.zpf) <= m.level_high)) p.fast = false;  // the constant tie margins assume |z| <= levels
     }
     __device__ __forceinline__ Par compute(const Stat& s) const {
@@ -78,6 +87,8 @@ struct IntPolicyT {
         int_params(s.lo, s.hi, m, p.scale, p.zpf, p.zpi);
         p.has_zp = m.asym;
         finish(p);
+        // quant_n_div: every quotient of the group must stay far from overflow (constant groups have scale = eps)
+        if (!(fmaxf(fabsf(s.lo), fabsf(s.hi)) * fabsf(p.r) <= 1.2676506002282294e+30f)) p.fast = false;
         return p;
     }
     __device__ __forceinline__ Par load(const GroupArgs& a, int64_t g) const {
@@ -177,6 +188,43 @@ struct IntPolicyT {
             for (int i = 0; i < C; ++i) k[c0 + i] = kc[i];
         }
     }
+    // k[i] <- clip(rne(RN(w/s) [+ z])) for N elements sharing parameters that were COMPUTED from these very elements
+    // (so a non-finite element has already made the scale non-finite and the group "not fast").  Straight-line and
+    // exact: the IEEE quotient comes from the correctly rounded reciprocal r = RN(1/s) by two correction steps,
+    //     q0 = RN(w r);  q1 = RN(q0 + (w - s q0) r);  q2 = RN(q1 + (w - s q1) r)
+    // (the residuals are exact in one fma).  q1 is within half an ulp + 2^-23 ulp of w/s, hence a faithful rounding,
+    // and Markstein's theorem (r correctly rounded, q faithful => RN(q + (w - s q) r) = RN(w/s)) makes q2 the
+    // correctly rounded quotient, so the sum with z and the rounding see what the reference's divide gives them.  No tie test, no branch: exact ties (w/s on x.5)
+    // are NOT rare for bf16 / f16 weights (8..11-bit significands: ~0.25 % of the elements of a N(0, 0.02) bf16
+    // tensor), which made 70 % of the 8-element chunks of a wave take the tie-test path's divergent re-computation
+    // -- a quarter of the kernel's issue slots.  The five multiply-adds are packed (v_pk_mul_f32 / v_pk_fma_f32:
+    // two elements per issue slot).  Scales outside [2^-60, 2^60] (residual under/overflow) take the IEEE divide.
+    template <int N>
+    __device__ __forceinline__ void quant_n_div(const Par& p, const float* f, float* k) const {
+        static_assert(N % 2 == 0, "pairs of elements");
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 r = {p.r, p.r}, ns = {-p.scale, -p.scale};
+        const float zf = p.has_zp ? p.zpf : 0.0f;
+        const f32x2 z = {zf, zf};
+        if (!p.fast) {  // (per lane; the wave skips the block unless one of its groups is out of range)
+#pragma unroll
+            for (int i = 0; i < N; ++i) k[i] = int_quant(f[i], p.scale, p.zpf, p.has_zp, m);
+        }
+        if (p.fast) {
+#pragma unroll
+            for (int i = 0; i < N; i += 2) {
+                const f32x2 w = {f[i], f[i + 1]};
+                f32x2 q = w * r;
+                f32x2 res = __builtin_elementwise_fma(q, ns, w);
+                q = __builtin_elementwise_fma(res, r, q);
+                res = __builtin_elementwise_fma(q, ns, w);
+                q = __builtin_elementwise_fma(res, r, q);
+                if (p.has_zp) q = q + z;
+                k[i] = __builtin_amdgcn_fmed3f(rintf(q.x), m.level_low, m.level_high);
+                k[i + 1] = __builtin_amdgcn_fmed3f(rintf(q.y), m.level_low, m.level_high);
+            }
+        }
+    }
     // 8 clipped codes -> one dword of nibbles, assembled in the float domain (exact integers < 2^16 per half)
     __device__ __forceinline__ uint32_t nibbles8(const float* k) const {
         const float p01 = fmaf(k[1], 16.0f, k[0]), p23 = fmaf(k[3], 16.0f, k[2]);
@@ -242,7 +290,7 @@ struct IntPolicyT {
     __device__ __forceinline__ void pack_lane(const Par* par, float* f, uint32_t* out) const {
         constexpr int SG = NE / GPL;
 #pragma unroll
-        for (int gi = 0; gi < GPL; ++gi) quant_n<SG>(par[gi], f + gi * SG, f + gi * SG);
+        for (int gi = 0; gi < GPL; ++gi) quant_n_div<SG>(par[gi], f + gi * SG, f + gi * SG);
 #pragma unroll
         for (int j = 0; j < NE / 8; ++j) out[j] = nibbles8(f + 8 * j);
     }

@@ -50,16 +50,16 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
     uint32_t* done = b.done + part * kClaimStride;
     const uint32_t cbase = lo;
     // team-uniform claim: a wave claims for itself, a block through thread 0 and LDS
-    uint32_t claim = 0;
+    claim_init();
     auto claim_issue = [&]() {
-        if (TEAM == 64 ? lane == 0 : threadIdx.x == 0) claim = claim_async(ctr);
+        if (TEAM == 64 ? lane == 0 : threadIdx.x == 0) claim_async(ctr);
     };
     auto claim_take = [&]() -> uint32_t {  // after the caller's vmcnt(0)
         if constexpr (TEAM == 64) {
-            return cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+            return cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_value());
         } else {
             // one barrier: the slot is rewritten two rounds later, with the statistics barrier in between
-            if (threadIdx.x == 0) claim_sh[parity] = claim;
+            if (threadIdx.x == 0) claim_sh[parity] = claim_value();
             __syncthreads();
             return cbase + claim_sh[parity];
         }
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
         }
     };
     claim_issue();
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t r = claim_take();
     parity ^= 1;  // (block teams) the slot just read must not be rewritten before everybody has read it
     if (r >= hi) {  // (a team makes exactly one failing claim, the last thing it does with the counter)
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
     else load_row(cd, cur);
     claim_issue();
     for (;;) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t rn = claim_take();  // (block teams: contains the barrier after which the whole image has landed)
         if constexpr (DMA) {
 #pragma unroll
@@ -185,12 +185,12 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
                     float f[2 * E];
                     unpack<DT>(opaque(cur[k]), f);
                     unpack<DT>(opaque(cur[k + 1]), f + E);
-                    pol.template quant_n<2 * E>(par, f, f);
+                    pol.template quant_n_div<2 * E>(par, f, f);
                     pol.template store_codes<2 * E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
                 } else if (j < cd.vpr) {
                     float f[E];
                     unpack<DT>(opaque(cur[k]), f);
-                    pol.template quant_n<E>(par, f, f);
+                    pol.template quant_n_div<E>(par, f, f);
                     pol.template store_codes<E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
                 }
             }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
                 if (j < cd.vpr) {
                     float f[E];
                     unpack<DT>(opaque(cur[k]), f);
-                    pol.template quant_n<E>(par, f, f);
+                    pol.template quant_n_div<E>(par, f, f);
                     pol.template store_codes<E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
                 }
             }
@@ -218,6 +218,129 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
         }
     }
     if (TEAM == 64 ? lane == 0 : threadIdx.x == 0) claim_done(ctr, done, b.teams_on[part]);  // rn was the failing claim
+}
+
+// One row per team, one launch-wide grid: the workgroup dispatcher hands out the rows in address order, occupancy
+// hides the load latency (experimental alternative to the claimed kernel above, NNCF_AMD_ROW_ONCE=1).
+template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED>
+__global__ __launch_bounds__(256) void k_rows_once(BatchArgs b) {
+    constexpr int E = Elem<DT>::kPerVec;
+    constexpr int TPB = 256 / TEAM;
+    __shared__ float lds[kPolicyLds];
+    __shared__ typename Policy::Stat wave_stat[4];
+    constexpr bool DMA = TEAM == 64 || KEEP <= 8;
+    __shared__ Vec16 stage[TEAM == 64 ? 4 : 1][DMA ? TEAM * KEEP : 1];
+    const int lane = threadIdx.x & 63;
+    const int tl = threadIdx.x % TEAM;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total = b.tile_start[b.n];
+    const uint32_t r = TEAM == 64 ? blockIdx.x * TPB + wave : blockIdx.x;
+    const bool have = r < total;
+    int lo_i = 0, hi_i = b.n;
+    while (have && hi_i - lo_i > 1) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (r >= b.tile_start[mid]) lo_i = mid;
+        else hi_i = mid;
+    }
+    const uint32_t vpr = b.nfull[lo_i];
+    const uint64_t row = have ? r - b.tile_start[lo_i] : 0;
+    constexpr bool PAIRS = DMA && KEEP >= 2;
+    auto vec_of = [&](int k) -> uint32_t {
+        return PAIRS ? (uint32_t)(2 * TEAM * (k >> 1) + 2 * tl + (k & 1)) : (uint32_t)(tl + k * TEAM);
+    };
+    Vec16 cur[KEEP];
+    if (have) {
+        if constexpr (DMA) {
+            const uint32_t lds_base = (uint32_t)(uintptr_t)stage[TEAM == 64 ? wave : 0];
+            const char* tbase = (const char*)b.w[lo_i] + row * vpr * 16;
+            const uint32_t last = (vpr - 1) * 16u;
+            const uint32_t w0 = TEAM == 64 ? 0u : (uint32_t)wave * 64u;
+#pragma unroll
+            for (int u = 0; u < KEEP; ++u) {
+                const uint32_t v = (uint32_t)(u * TEAM) + w0;
+                const uint32_t off = (v + lane) * 16u;
+                dma16_nt(tbase, off < last ? off : last, lds_base + v * 16u);
+            }
+        } else {
+            const Vec16* src = (const Vec16*)b.w[lo_i] + row * vpr;
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const uint32_t j = tl + k * TEAM;
+                if (j < vpr) cur[k] = load16_nt(src + j);
+            }
+        }
+    }
+    Policy::init_shared(lds);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // policy tables; block teams: the whole image has landed
+    if (!have) return;  // (a whole block for block teams; wave teams have no barrier below)
+    GroupArgs o = {};
+    o.mode = b.mode;
+    const Policy pol(o, lds);
+    if constexpr (DMA) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) cur[k] = stage[TEAM == 64 ? wave : 0][vec_of(k)];
+    }
+    typename Policy::Stat st = pol.stat_init();
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const uint32_t j = vec_of(k);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j < vpr) {
+            float f[E];
+            unpack<DT>(cur[k], f);
+            pol.template stat_add_vec<E>(st, f);
+        }
+    }
+    pol.template stat_lanes<64>(st);
+    if constexpr (TEAM != 64) {
+        if (lane == 0) wave_stat[wave] = st;
+        __syncthreads();
+        st = wave_stat[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) pol.stat_merge(st, wave_stat[q]);
+    }
+    const typename Policy::Par par = pol.compute(st);
+    o.scale_out = b.scale[lo_i];
+    o.zp_out = (int32_t*)b.aux[lo_i];
+    if (tl == 0) pol.template store<true>(o, (int64_t)row, par);
+    if constexpr (PACKED) o.packed = b.packed[lo_i];
+    else o.codes = b.packed[lo_i];
+    auto opaque = [](Vec16 raw) {
+        asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));
+        return raw;
+    };
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int k = 0; k < KEEP; k += 2) {
+            const uint32_t j = vec_of(k);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < vpr) {
+                float f[2 * E];
+                unpack<DT>(opaque(cur[k]), f);
+                unpack<DT>(opaque(cur[k + 1]), f + E);
+                pol.template quant_n_div<2 * E>(par, f, f);
+                pol.template store_codes<2 * E, true>(o, f, (int64_t)((row * vpr + j) * E));
+            } else if (j < vpr) {
+                float f[E];
+                unpack<DT>(opaque(cur[k]), f);
+                pol.template quant_n_div<E>(par, f, f);
+                pol.template store_codes<E, true>(o, f, (int64_t)((row * vpr + j) * E));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const uint32_t j = vec_of(k);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j < vpr) {
+                float f[E];
+                unpack<DT>(opaque(cur[k]), f);
+                pol.template quant_n_div<E>(par, f, f);
+                pol.template store_codes<E, true>(o, f, (int64_t)((row * vpr + j) * E));
+            }
+        }
+    }
 }
 
 // team/keep class of a row of `vpr` 16-byte vectors; 0 = does not fit (longer than 4096 vectors)
@@ -245,7 +368,7 @@ static hipError_t launch_rows(BatchArgs& b, hipStream_t s) {
     // (8 KiB and 28 KiB rows): 32 parts 0.63, 16: 0.66, 8: 0.68 of the roofline, 4: 0.52 (one address sustains ~10^8
     // atomics/s) -- so the count follows the shortest row of the launch: ~6 x 10^7 claims/s per counter at the
     // ~3.6 TB/s the rows are read with.
-    static const int forced = tile_knob("NNCF_AMD_ROW_CLAIM_GROUPS", 1, kClaimGroups, 0);
+    static const int forced = tile_knob("NNCF_AMD_ROW_CLAIM_GROUPS", 1, kClaimGroupsUsed, 0);
     uint32_t min_vpr = 0xffffffffu;
     for (int j = 0; j < b.n; ++j) min_vpr = b.nfull[j] < min_vpr ? b.nfull[j] : min_vpr;
     int groups = 8;
@@ -253,6 +376,11 @@ static hipError_t launch_rows(BatchArgs& b, hipStream_t s) {
     if (forced > 0 && (forced & (forced - 1)) == 0) groups = forced;
     constexpr int TPB = 256 / TEAM;
     const int64_t blocks = ((int64_t)b.tile_start[b.n] + TPB - 1) / TPB;
+    static const int once = tile_knob("NNCF_AMD_ROW_ONCE", 0, 1, 0);
+    if (once) {
+        hipLaunchKernelGGL((k_rows_once<Policy, DT, TEAM, KEEP, PACKED>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+        return hipPeekAtLastError();
+    }
     return launch_claimed(k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>, (int)(blocks < resident ? blocks : resident), TPB, b, s,
                           1, groups);
 }
