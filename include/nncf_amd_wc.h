@@ -6,12 +6,9 @@
  *  - every pointer argument is a DEVICE pointer unless its name ends in `_host`;
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
  *    stream-ordered and asynchronous; no entry point allocates or synchronizes;
- *  - global state: read-only tables; the scratch array of nncf_amd_int_quant_error_static; and the work-claim
- *    counters of the *_batched lowering calls (a 1 MiB device array per GPU, one slot per stream, up to 32 streams
- *    per GPU).  The kernels leave those counters at zero, the host keeps no copy of them: a batched call may be
- *    recorded into a HIP graph and replayed, as long as launches that share a slot (= were issued on the same
- *    stream) never run at the same time.  After a launch that did not run to its end (device fault, aborted
- *    process group) call nncf_amd_reset_claims();
+ *  - global state: read-only tables and the scratch array of nncf_amd_int_quant_error_static, nothing else: the
+ *    multi-tensor (*_batched) kernels keep no counters or queues, so a call may be issued on any number of streams
+ *    at once and recorded into a HIP graph and replayed;
  *  - the caller owns every buffer; "nullable" outputs are skipped when NULL;
  *  - return value: NNCF_AMD_OK (0) or a negative nncf_amd_status; nncf_amd_last_error()
  *    gives a thread-local message for the last failure;
@@ -67,10 +64,6 @@ typedef enum { NNCF_AMD_ERR_MAX_MEAN = 0, NNCF_AMD_ERR_FROBENIUS = 1 } nncf_amd_
 int nncf_amd_version(void);               /* major*10000 + minor*100 + patch */
 const char* nncf_amd_last_error(void);    /* thread-local, never NULL         */
 const char* nncf_amd_status_string(int status);
-
-/* Zeroes the work-claim counters of the current device, stream-ordered on `stream` (no counterpart in the reference:
- * housekeeping of this library's multi-tensor kernels; only needed after a launch that did not finish). */
-int nncf_amd_reset_claims(void* stream);
 
 /*
  * Fused integer lowering: group min/max -> scale[, zero point] -> round -> clip [-> nibble pack] [-> dequantize].

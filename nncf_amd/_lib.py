@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("NNCF_AMD_LIB") or os.path.join(_HERE, "libnncf_amd_wc
 
 F32, F16, BF16 = 0, 1, 2
 ZP_NONE, ZP_I32, ZP_F32 = 0, 1, 2
-MAX_BATCH = 80  # tensors per launch of the multi-tensor kernels (csrc/wc_group_kernels.h: kMaxBatch)
+MAX_BATCH = 92  # tensors per launch of the multi-tensor kernels (csrc/wc_group_kernels.h: kMaxBatch)
 MODE_ID = {"int8_asym": 0, "int8_sym": 1, "int4_asym": 2, "int4_sym": 3, "nf4": 4, "mxfp4": 5, "fp4": 6}
 
 OK, ERR_BAD_ARG, ERR_GROUP_SIZE, ERR_DTYPE, ERR_MODE, ERR_LAUNCH, ERR_WORKSPACE, ERR_UNSUPPORTED = (
@@ -24,7 +24,6 @@ SIGNATURES = {
     "nncf_amd_version": (c_int, []),
     "nncf_amd_last_error": (c_char_p, []),
     "nncf_amd_status_string": (c_char_p, [c_int]),
-    "nncf_amd_reset_claims": (c_int, [c_void_p]),
     "nncf_amd_int_quantize": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nncf_amd_int_quantize_batched": (c_int, [c_int, POINTER(c_void_p), c_int, POINTER(c_int64), POINTER(c_int64),

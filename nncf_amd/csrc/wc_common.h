@@ -38,14 +38,6 @@ struct OncePerDevice {
     }
 };
 
-// Work-claim counters of the multi-tensor kernels (wc_group_kernels.h, wc_row_kernels.h); state in wc_misc.hip.
-// kClaimSlots slots per GPU, each kClaimGroups counters kClaimStride words apart (one 128-byte line per counter).
-constexpr int kClaimSlots = 32, kClaimGroups = 128, kClaimStride = 32, kClaimDevices = 64;
-// Counter slot for a launch on stream `s` of the current device: launches on one stream run one after another and
-// share a slot; every other stream seen gets its own (the table holds kClaimSlots streams per device and recycles
-// the least recently used entry beyond that).  *ctr / *done: device addresses of the slot's claim / done counters.
-hipError_t claim_slot(hipStream_t s, uint32_t** ctr, uint32_t** done);
-
 // ---------------------------------------------------------------- 16-byte vectors of the input dtype
 struct alignas(16) Vec16 {
     uint32_t w[4];

@@ -17,10 +17,6 @@
 //   float dq(int code, float value, const Par&);  int nibble(int code)
 //   template<int E> void stat_add_vec(Stat&, const float*); template<int E> void emit(args, par, f, v)  vector forms
 #pragma once
-#include <stdlib.h>
-
-#include <mutex>
-
 #include "wc_common.h"
 
 namespace wc {
@@ -213,23 +209,21 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ grouped, multi-tensor
-// The data-free compress path over MANY tensors in one launch: a launch boundary costs ~4 us of ramp-up, drain and
-// dispatch on MI355X, as much as compressing an 8 MB tensor, so per-tensor launches cap a whole-model pass well
-// below the HBM rate.  Tensors are cut into the same 64*VPL-vector tiles; tile ids run through all tensors of the
-// batch (tile_start = prefix sums) and the resident waves stride over them, prefetching their next tile by LDS-DMA
-// while they work on the current one.  Always "lean": packed codes + computed parameters only.
-#ifndef WC_ABL
-#define WC_ABL 0  // developer builds: bit 0 no parameter stores, 1 no code stores, 2 no loads, 3 no arithmetic
-#endif
-constexpr int kMaxBatch = 80;  // sizeof(BatchArgs) must stay under the 4 KiB of kernel arguments
-#ifndef WC_GROUPS
-#define WC_GROUPS 32
-#endif
-constexpr int kClaimGroupsUsed = WC_GROUPS;
-constexpr int kClaimChunk = 3;       // tiles handed out per claim by the multi-tensor tile kernel
-constexpr int kTileClaimGroups = 8;  // parts (sequential streams) of its tile range
-constexpr int kTileBlocksPerCU = 3;  // resident blocks per CU it is launched with
-constexpr int kBatchGrid = 2048;  // 256 CUs x 8 blocks; the resident waves stride over the rest
+// The data-free compress path over MANY tensors in one launch (a launch boundary costs ~10 us of ramp-up, drain and
+// dispatch on MI355X, as much as compressing a 20 MB tensor).  Tensors are cut into the same 64*VPL-vector tiles;
+// tile ids run through all tensors of the batch (tile_start = prefix sums).  Always "lean": packed codes +
+// computed parameters only.
+//
+// ONE TILE PER WAVE, a grid of tiles/4 blocks: the hardware's workgroup dispatcher hands out the tiles in address
+// order as waves retire, and occupancy (6 blocks = 24 waves = 96 KiB of tiles in flight per CU) hides the load
+// latency.  Measured on MI355X (bench.py, Llama-3-8B INT4_SYM g128): 0.762 of the 8 TB/s roofline, the rate of a
+// pure-traffic probe of the same shape (tools/probe.hip: 0.77).  The kernel this replaces kept one resident set of
+// waves alive over the whole launch -- tiles claimed from per-part atomic counters, the next tile prefetched by
+// LDS-DMA under the arithmetic, a second LDS image per wave in its last version -- and stopped at 0.71 whatever
+// was tuned (blocks per CU, parts, tiles per claim): ablation builds showed its data movement alone at 0.72-0.73
+// with the packed stores and at 0.77 without them, i.e. the persistent waves' store stream, not their loads or
+// their arithmetic, held it back; short-lived waves in dispatch order do not have that problem.
+constexpr int kMaxBatch = 92;  // sizeof(BatchArgs) must stay under the 4 KiB of kernel arguments
 struct BatchArgs {
     int n;
     int mode;
@@ -240,26 +234,8 @@ struct BatchArgs {
     uint8_t* packed[kMaxBatch];
     float* scale[kMaxBatch];
     void* aux[kMaxBatch];  // int32 zero points (asymmetric integer modes) or uint8 E8M0 scales (MXFP4); may be NULL
-    uint32_t* ctr;                  // claim counters of this launch's slot (kClaimStride words apart), zero at launch
-    uint32_t* done;                 // per part: teams that have made their failing claim (same stride), zero at launch
-    uint32_t log2_groups;           // claim groups of this launch = 1 << log2_groups (<= grid)
-    uint32_t chunk;                 // tiles per claim (k_grouped_batch; 1 for the row kernels' units)
-    uint32_t teams_on[kClaimGroupsUsed];  // teams (waves or blocks) that serve each part
-    uint32_t part_lo[kClaimGroupsUsed + 1];  // tile range of each part (proportional to the blocks serving it)
 };
-static_assert(kClaimGroupsUsed <= kClaimGroups, "parts of a launch <= counters of a slot");
 static_assert(sizeof(BatchArgs) <= 4096, "BatchArgs is passed by value as the kernel argument");
-// Tile claim counters.  Waves make unequal progress (the hardware favours the oldest waves: with a static stride
-// the first blocks finish in half the time of the last ones and the launch ends in a long under-occupied tail), so
-// tiles are claimed: the tile range is cut into 2^k contiguous parts, block x serves part (x / 8) mod 2^k (eight
-// consecutive blocks sit on the eight XCDs: every part is served by all XCDs and by old and young blocks alike),
-// and a wave takes the next tile of its part with one returning atomic add (several counters, because one
-// address sustains only ~10^8 atomics/s).
-// The counters clean up after themselves: every team stops at its first failed claim and then adds one to the part's
-// `done` counter; the team that brings it to the number of teams serving the part knows that nobody will touch the
-// part's counters again and writes both back to zero.  A launch therefore finds zeros and leaves zeros, the host
-// keeps no copy of device state, and a recorded launch (HIP graph) can be replayed.  The state itself (one device
-// array per GPU, slots handed out per stream) lives in wc_misc.hip: claim_slot().
 constexpr int64_t kMaxBatchVec = (int64_t)1 << 30;  // vectors per tensor and per launch (32-bit tile / group indices)
 
 // appends tensor j (nvec 16-byte vectors) to a batch; returns the running tile count
@@ -279,34 +255,6 @@ static inline uint32_t batch_set(BatchArgs& b, int j, uint32_t acc, int64_t nvec
 }
 
 // one 16-byte-per-lane LDS-DMA load, non-temporal: global (SGPR base + 32-bit VGPR offset) -> LDS (M0 + lane*16).
-// Written out so that the issue path holds no VALU instruction at all (a VALU op there queues behind the other
-// waves' arithmetic and delays the load by up to a whole compute phase).
-// Returning atomic add of 1 on a wave-uniform address, issued by the calling lanes; the result arrives later, behind
-// a vmcnt wait of the caller's choosing.  It arrives in the accumulation register a0 (a1 holds the addend), NOT in a
-// register the compiler allocates: an asm output that is written asynchronously can be copied by the compiler
-// before the data is there and copied back over it afterwards (seen in a loop with two call sites: every claim of a
-// wave was read as the first one).  The compiler does not touch a0 / a1 in these kernels (no MFMA, no spills: the
-// AGPR count of every instantiation is 2, checked at build time by tools/check_kernel_regs.py).
-__device__ __forceinline__ void claim_init() { asm volatile("v_accvgpr_write_b32 a1, 1" ::: "a1"); }
-__device__ __forceinline__ void claim_async(uint32_t* ctr) {
-    const uint32_t zero = 0;
-    asm volatile("global_atomic_add a0, %0, a1, %1 sc0 sc1" : : "v"(zero), "s"(ctr) : "memory", "a0");  // sc0: return, sc1: agent scope
-}
-// the value of the claim issued last by this lane; valid after a vmcnt wait that covers it
-__device__ __forceinline__ uint32_t claim_value() {
-    uint32_t v;
-    asm volatile("v_accvgpr_read_b32 %0, a0" : "=v"(v) : : "memory", "a0");
-    return v;
-}
-// Called by ONE lane of a team after its failing claim has RETURNED (so the claim was performed before this add is
-// issued): the last team of the part puts the part's two counters back to zero for the next launch.
-__device__ __forceinline__ void claim_done(uint32_t* ctr, uint32_t* done, uint32_t teams) {
-    const uint32_t d = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d + 1 == teams) {
-        __hip_atomic_exchange(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_exchange(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
 __device__ __forceinline__ void dma16_nt(const char* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
                  :
@@ -314,262 +262,13 @@ __device__ __forceinline__ void dma16_nt(const char* sbase, uint32_t voff, uint3
                  : "memory", "m0");
 }
 
-// Per-wave schedule: TWO tiles of 64*VPL vectors in flight per wave (two wave-private LDS images), the current tile
-// processed from registers:
-//     wait DMA(t) [DMA(t+1) stays in flight] -> LDS image to registers -> store the PREVIOUS tile's packed codes and
-//     group parameters -> (claim) -> issue DMA(t+2) into the image just read -> statistics, parameters, quantize +
-//     pack (kept in registers until the next round)
-// Why two images: a wave that finds its tile landed still needs issue slots for the four LDS reads and the DMA of
-// its next tile, and the SIMD hands those out oldest wave first -- behind the arithmetic of the other waves the
-// turn-round of a single image took up to a whole compute phase, during which the wave had nothing in flight.
-// Every output store of a tile is deferred to the next round and placed BEFORE the DMA issue, so the youngest
-// VPL vector-memory operations at the top of the loop are exactly DMA(t+1): `s_waitcnt vmcnt(VPL)` waits for
-// DMA(t), the claim and the stores but not for the tile behind (vmcnt counts loads, stores and atomics in issue
-// order).  The tensor descriptors of the three tiles stay in SGPRs and are reloaded from the kernel arguments only
-// when a wave crosses into another tensor.
+// Per wave: locate the tensor of its tile (binary search over the prefix sums, scalar), 4 DMA instructions bring the
+// tile into the wave's LDS image (source addresses permuted as in k_grouped; a partial tile clamps to its last
+// vector), every lane reads its 64 contiguous bytes back, min/max over the group's lanes by DPP, parameters,
+// exact quantization (Policy::pack_lane), one 16-byte store of packed codes per lane, parameter stores by the
+// group's first lane.
 template <typename Policy, int DT, int VPG>
 __global__ __launch_bounds__(256) void k_grouped_batch(BatchArgs b) {
-    constexpr int VPL = kVPL;
-    static_assert(VPL == 4, "the loop's s_waitcnt vmcnt(4) is the number of DMA instructions per tile");
-    constexpr int E = Elem<DT>::kPerVec;
-    constexpr int NE = VPL * E;
-    constexpr int GPL = VPG >= VPL ? 1 : VPL / VPG;
-    constexpr int LPG = VPG >= VPL ? VPG / VPL : 1;
-    constexpr int SG = NE / GPL;
-    constexpr int TILE = 64 * VPL;
-    constexpr int NW = NE / 8;  // packed dwords per lane
-    __shared__ Vec16 stage[4][2][TILE];
-    __shared__ __align__(16) float lds[kPolicyLds];
-    Policy::init_shared(lds);
-    __syncthreads();
-    GroupArgs o = {};
-    o.mode = b.mode;
-    const Policy pol(o, lds);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t lds_base = (uint32_t)(uintptr_t)stage[wave];
-    uint32_t src_off[VPL];
-#pragma unroll
-    for (int u = 0; u < VPL; ++u) {
-        const int sidx = u * 64 + lane;
-        src_off[u] = (uint32_t)((sidx & ~3) + ((sidx & 3) ^ ((sidx >> 4) & 3))) * 16u;
-    }
-    const int rot = (lane >> 2) & 3;
-    struct Desc {  // wave-uniform
-        uint32_t start, end, nfull, rem;
-        const char* w;
-        uint8_t* packed;
-        float* scale;
-        void* aux;
-    };
-    auto load_desc = [&](int i) {
-        Desc d;
-        d.start = b.tile_start[i];
-        d.end = b.tile_start[i + 1];
-        d.nfull = b.nfull[i];
-        d.rem = b.rem[i];
-        d.w = (const char*)b.w[i];
-        d.packed = b.packed[i];
-        d.scale = b.scale[i];
-        d.aux = b.aux[i];
-        return d;
-    };
-    auto issue_dma = [&](uint32_t t, const Desc& d, int q) {
-        const uint32_t lt = t - d.start;  // tile inside the tensor
-        const char* tbase = d.w + (uint64_t)lt * (TILE * 16);
-        const uint32_t image = lds_base + (uint32_t)q * (TILE * 16);
-        if (lt < d.nfull) {
-#pragma unroll
-            for (int u = 0; u < VPL; ++u) dma16_nt(tbase, src_off[u], image + u * 1024);
-        } else {
-            const uint32_t last = (d.rem - 1) * 16u;  // partial tile: clamp to the last valid vector
-#pragma unroll
-            for (int u = 0; u < VPL; ++u) dma16_nt(tbase, src_off[u] < last ? src_off[u] : last, image + u * 1024);
-        }
-    };
-    auto store_packed = [&](uint8_t* dst, const uint32_t* w) {
-        if constexpr (NW == 1) st<true>((uint32_t*)dst, w[0]);
-        if constexpr (NW == 2) st<true>((u32x2*)dst, u32x2{w[0], w[1]});
-        if constexpr (NW == 4) st<true>((u32x4*)dst, u32x4{w[0], w[1], w[2], w[3]});
-    };
-    // this block's part of the tile range and its claim counter
-    const uint32_t part = (blockIdx.x >> 3) & ((1u << b.log2_groups) - 1);
-    const uint32_t lo = b.part_lo[part], hi = b.part_lo[part + 1];
-    uint32_t* ctr = b.ctr + part * kClaimStride;
-    uint32_t* done = b.done + part * kClaimStride;
-    // a claim hands out `chunk` consecutive tiles: claimed value v -> tiles lo + v * chunk ...
-    const uint32_t chunk = b.chunk;
-    claim_init();
-    // The wave's tile sequence, in prefetch order.  `claim` is always in flight while a chunk is being handed out;
-    // the caller makes sure it has landed (a vmcnt wait that covers it) before a call that may start a new chunk.
-    // A wave makes exactly one failing claim, the last thing it does with the counter.
-    uint32_t nxt = 0, nxt_end = 0;  // next tile to hand out, end of its chunk
-    bool more = true;
-    auto next_tile = [&]() -> uint32_t {  // hi: no more tiles
-        if (nxt < nxt_end) return nxt++;
-        if (!more) return hi;
-        const uint32_t c = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_value()) * chunk;
-        if (c >= hi) {
-            more = false;
-            return hi;
-        }
-        nxt_end = c + chunk < hi ? c + chunk : hi;
-        nxt = c + 1;
-        if (lane == 0) claim_async(ctr);
-        return c;
-    };
-    if (lane == 0) claim_async(ctr);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t t = next_tile();
-    if (t >= hi) {
-        if (lane == 0) claim_done(ctr, done, b.teams_on[part]);
-        return;
-    }
-#ifdef WC_CLK  // developer build: per-wave start/end times into scale[0] (read back by tools/kbench.hip, WC_CLK=<file>)
-    const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
-    uint64_t ph[4] = {0, 0, 0, 0}, ntile = 0;  // cycles in: top wait, LDS read, stores + DMA issue, arithmetic
-#define WC_STAMP(k) { const uint64_t now_ = __builtin_readcyclecounter(); ph[k] += now_ - last_; last_ = now_; }
-#else
-#define WC_STAMP(k)
-#endif
-    int i = 0;
-    while (t >= b.tile_start[i + 1]) ++i;
-    Desc cur = load_desc(i);
-    issue_dma(t, cur, 0);
-    if (nxt >= nxt_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (one-tile chunks)
-    uint32_t t1 = next_tile();
-    Desc d1 = cur;
-    if (t1 < hi) {
-        if (t1 >= d1.end) {
-            do ++i; while (t1 >= b.tile_start[i + 1]);
-            d1 = load_desc(i);
-        }
-        issue_dma(t1, d1, 1);
-    }
-    int q = 0;  // image of the current tile
-    uint32_t round = 0;
-    // outputs of the previous tile, stored at the start of the next round
-    uint32_t pend[NW];
-    uint8_t* pend_dst = nullptr;  // per lane; NULL = nothing pending
-    typename Policy::Par pend_par[GPL];
-    uint32_t pend_g0 = 0;
-    bool pend_lead = false;  // this lane stores the parameters of its groups
-    GroupArgs po = o;        // the previous tile's parameter outputs
-    for (;;) {
-#ifdef WC_CLK
-        uint64_t last_ = __builtin_readcyclecounter();
-        ++ntile;
-#endif
-#if WC_ABL & 4
-        // (no loads to wait for; the stores are left in flight)
-#else
-        // DMA(t) is followed by: the stores of its own round (>= 1 instruction from round 1 on), DMA(t+1) (4) and
-        // the stores of the round after (>= 1).  From round 3 on at least 6 younger operations exist; all but the 5
-        // youngest are waited for, which also covers a claim issued in the last round (it sits before that round's DMA).
-        if (t1 >= hi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (round >= 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#endif
-        WC_STAMP(0)
-        float f[NE];
-        {
-            const Vec16* img = stage[wave][q];
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) {
-                const Vec16 raw = img[lane * VPL + (k ^ rot)];
-                unpack<DT>(raw, f + k * E);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        WC_STAMP(1)
-        uint32_t t2 = hi;
-        Desc d2 = d1;
-        if (t1 < hi) {
-            t2 = next_tile();
-            if (t2 < hi) {
-                if (t2 >= d2.end) {
-                    do ++i; while (t2 >= b.tile_start[i + 1]);
-                    d2 = load_desc(i);
-                }
-#if !(WC_ABL & 4)
-                issue_dma(t2, d2, q);
-#endif
-            }
-        }
-        asm volatile("" ::: "memory");  // the stores below stay younger than the DMA above
-#if !(WC_ABL & 2)
-        if (pend_dst) store_packed(pend_dst, pend);
-#endif
-#if !(WC_ABL & 1)
-        if (pend_lead) {
-#pragma unroll
-            for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(po, pend_g0 + gi, pend_par[gi]);
-        }
-#endif
-        WC_STAMP(2)
-        const uint32_t lt = t - cur.start;
-        const uint32_t in_tile = lt < cur.nfull ? (uint32_t)TILE : cur.rem;
-        const bool live = (uint32_t)(lane * VPL) < in_tile;  // rem % VPL == 0 (host): a lane is all live or all dead
-        const uint32_t v0 = lt * TILE + lane * VPL;          // first vector of this lane, < 2^30
-#if WC_ABL & 8
-#pragma unroll
-        for (int j = 0; j < NW; ++j) pend[j] = __float_as_uint(f[j] + f[j + NW]);
-#else
-#pragma unroll
-        for (int gi = 0; gi < GPL; ++gi) {
-            typename Policy::Stat st = pol.stat_init();
-            pol.template stat_add_vec<SG>(st, f + gi * SG);
-            if constexpr (LPG > 1) pol.template stat_lanes<LPG>(st);
-            pend_par[gi] = pol.compute(st);
-        }
-        pol.template pack_lane<NE, GPL>(pend_par, f, pend);
-#endif
-        pend_dst = live ? cur.packed + (uint64_t)v0 * (E / 2) : nullptr;
-        pend_lead = live && (lane & (LPG - 1)) == 0;
-        pend_g0 = v0 / VPG;
-        po.scale_out = cur.scale;
-        po.zp_out = (int32_t*)cur.aux;
-        po.e8m0_out = (uint8_t*)cur.aux;
-#ifdef WC_CLK
-        asm volatile("" : "+v"(pend[0]));
-#endif
-        WC_STAMP(3)
-        if (t1 >= hi) break;
-        t = t1;
-        cur = d1;
-        t1 = t2;
-        d1 = d2;
-        q ^= 1;
-        ++round;
-    }
-    if (pend_dst) store_packed(pend_dst, pend);
-    if (pend_lead) {
-#pragma unroll
-        for (int gi = 0; gi < GPL; ++gi) pol.template store<true>(po, pend_g0 + gi, pend_par[gi]);
-    }
-    // every claim issued has been consumed: the one consumed last was the failing one, and it has returned
-    if (lane == 0) claim_done(ctr, done, b.teams_on[part]);
-#ifdef WC_CLK
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63) == 0) {
-        uint64_t* rec = (uint64_t*)b.scale[0] + (size_t)(blockIdx.x * 4 + wave) * 8;
-        rec[0] = rt0;
-        rec[1] = __builtin_amdgcn_s_memrealtime();
-        rec[2] = __builtin_readcyclecounter() - clk0;
-        rec[3] = ntile;
-        rec[4] = ph[0];
-        rec[5] = ph[1];
-        rec[6] = ph[2];
-        rec[7] = ph[3];
-    }
-#endif
-}
-
-// One tile per wave, one launch-wide grid of tiles/4 blocks: the hardware's workgroup dispatcher hands out the tiles
-// (in address order), occupancy hides the load latency.  Experimental alternative to the persistent claimed kernel
-// above (NNCF_AMD_TILE_ONCE=1).
-template <typename Policy, int DT, int VPG>
-__global__ __launch_bounds__(256) void k_grouped_once(BatchArgs b) {
     constexpr int VPL = kVPL;
     constexpr int E = Elem<DT>::kPerVec;
     constexpr int NE = VPL * E;
@@ -647,82 +346,13 @@ __global__ __launch_bounds__(256) void k_grouped_once(BatchArgs b) {
     }
 }
 
-// blocks of `kernel` the device holds at once (cached by the caller per kernel instantiation)
-template <typename Kernel>
-static int resident_blocks(Kernel kernel, int max_per_cu = 0) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess ||
-        hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
-        return kBatchGrid;
-    if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;
-    return per_cu * prop.multiProcessorCount;
-}
-
-// Launches a kernel whose teams (`teams_per_block` per block) claim work units: takes the stream's counter slot and
-// fills in the parts and the number of teams that serve each (the kernel's clean-up needs it).
-template <typename Kernel>
-static hipError_t launch_claimed(Kernel kernel, int blocks, int teams_per_block, BatchArgs& b, hipStream_t s,
-                                 uint32_t chunk = 1, int groups_used = kClaimGroupsUsed) {
-    const uint32_t units = b.tile_start[b.n];
-    if (blocks < 1) return hipSuccess;
-    if (groups_used > kClaimGroupsUsed) groups_used = kClaimGroupsUsed;  // BatchArgs holds that many parts
-    int lg = 0;
-    while ((16 << lg) <= blocks && (2 << lg) <= groups_used) ++lg;  // at least one octet of blocks per part
-    const int groups = 1 << lg;
-    uint32_t blocks_on[kClaimGroups] = {};
-    for (int x = 0; x < blocks; ++x) ++blocks_on[(x >> 3) & (groups - 1)];
-    hipError_t e = claim_slot(s, &b.ctr, &b.done);
-    if (e != hipSuccess) return e;
-    b.log2_groups = (uint32_t)lg;
-    b.chunk = chunk;
-    uint32_t seen = 0;
-    for (int g = 0; g < groups; ++g) {
-        b.teams_on[g] = (uint32_t)teams_per_block * blocks_on[g];
-        b.part_lo[g] = (uint32_t)((uint64_t)units * seen / (uint32_t)blocks);
-        seen += blocks_on[g];
-    }
-    b.part_lo[groups] = units;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
-    return hipPeekAtLastError();
-}
-
-// grid of a multi-tensor launch: one resident set of blocks (never a second, under-occupied round), at most one
-// wave per tile.
-// developer knobs of the tile kernel's launch shape (environment, read once); defaults = the measured optimum
-static int tile_knob(const char* name, int lo, int hi, int dflt) {
-    const char* e = getenv(name);
-    const int v = e ? atoi(e) : 0;
-    return (v >= lo && v <= hi) ? v : dflt;
-}
-
-template <typename Policy, int DT, int VPG>
-static hipError_t launch_batch_kernel(BatchArgs& b, hipStream_t s) {
-    // Measured on MI355X (bench.py, Llama-3-8B INT4_SYM g128; the other modes move the same way): the HBM system
-    // saturates at 3 blocks (12 waves, 48 KiB of tiles in flight) per CU -- 1: 0.31, 2: 0.59, 3: 0.69, 4: 0.68,
-    // 6 (occupancy limit): 0.67 of the roofline -- and likes FEW sequential streams: 64 parts 0.66, 32: 0.69,
-    // 16: 0.70; below that one counter per part runs into the ~10^8 atomics/s an address sustains (8 parts: 0.42),
-    // so a claim hands out kClaimChunk consecutive tiles: 8 parts x 3 tiles 0.71.
-    static const int per_cu = tile_knob("NNCF_AMD_BLOCKS_PER_CU", 1, 16, kTileBlocksPerCU);
-    static const int resident = resident_blocks(k_grouped_batch<Policy, DT, VPG>, per_cu);
-    static const uint32_t chunk = (uint32_t)tile_knob("NNCF_AMD_CLAIM_CHUNK", 1, 64, kClaimChunk);
-    static const int groups = [] {
-        const int v = tile_knob("NNCF_AMD_CLAIM_GROUPS", 1, kClaimGroupsUsed, kTileClaimGroups);
-        return (v & (v - 1)) == 0 ? v : kTileClaimGroups;
-    }();
-    const int64_t blocks = ((int64_t)b.tile_start[b.n] + 3) / 4;
-    static const int once = tile_knob("NNCF_AMD_TILE_ONCE", 0, 1, 0);
-    if (once) {
-        hipLaunchKernelGGL((k_grouped_once<Policy, DT, VPG>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-        return hipPeekAtLastError();
-    }
-    return launch_claimed(k_grouped_batch<Policy, DT, VPG>, (int)(blocks < resident ? blocks : resident), 4, b, s, chunk,
-                          groups);
-}
 
 template <typename Policy, int DT, int VPG>
 static void launch_batch(BatchArgs& b, hipStream_t s) {
-    (void)launch_batch_kernel<Policy, DT, VPG>(b, s);  // errors surface through launch_status()
+    const int64_t blocks = ((int64_t)b.tile_start[b.n] + 3) / 4;  // < 2^29
+    if (blocks > 0)
+        hipLaunchKernelGGL((k_grouped_batch<Policy, DT, VPG>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+    // errors surface through launch_status()
 }
 
 template <typename Policy, int DT>
@@ -943,16 +573,16 @@ template <typename Policy, int DT, int VPG>
 static void launch_grouped(const GroupArgs& a, hipStream_t s) {
     const int64_t nvec = a.n_groups * VPG;
     const int64_t tiles = (nvec + 64 * kVPL - 1) / (64 * kVPL);
-    // 256 CUs x 8 resident blocks; more tiles than that are strided over by the resident waves
+    // 256 CUs x 8 resident blocks; more tiles than that are strided over by the resident waves (k_grouped)
     int64_t blocks = (tiles + 3) / 4;
-    if (blocks > kBatchGrid) blocks = kBatchGrid;
+    if (blocks > 2048) blocks = 2048;
     const bool lean = a.packed && a.scale_out && !a.scale_in && !a.codes && !a.values && !a.dq && nvec <= kMaxBatchVec;
     if (lean) {
         BatchArgs b = {};
         b.n = 1;
         b.mode = a.mode;
         batch_set(b, 0, 0, nvec, a.w, a.packed, a.scale_out, a.zp_out ? (void*)a.zp_out : (void*)a.e8m0_out);
-        (void)launch_batch_kernel<Policy, DT, VPG>(b, s);
+        launch_batch<Policy, DT, VPG>(b, s);
     } else {
         hipLaunchKernelGGL((k_grouped<Policy, DT, VPG, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     }

@@ -27,59 +27,6 @@ int launch_status(const char* what) {
     return NNCF_AMD_OK;
 }
 
-// ------------------------------------------------------------------ work-claim counter slots
-// [0]: claim counters, [1]: done counters.  Kernels leave every counter at zero (see claim_done), so the host keeps
-// no copy of their values; nncf_amd_reset_claims() zeroes them after a launch that did not run to its end.
-static __device__ __align__(256) uint32_t g_claim[2][kClaimSlots][kClaimGroups][kClaimStride];
-struct ClaimDevice {
-    uint32_t* base = nullptr;  // device address of g_claim on this device
-    hipStream_t stream[kClaimSlots] = {};
-    uint64_t used[kClaimSlots] = {};  // 0: free; else the tick of the slot's last use
-    uint64_t tick = 0;
-};
-static ClaimDevice g_claim_dev[kClaimDevices];
-static std::mutex g_claim_mutex;
-
-static hipError_t claim_device(ClaimDevice** out) {
-    int dev = -1;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= kClaimDevices) return hipErrorInvalidDevice;
-    ClaimDevice& d = g_claim_dev[dev];
-    if (!d.base) {
-        uint32_t* sym = nullptr;
-        e = hipGetSymbolAddress((void**)&sym, HIP_SYMBOL(g_claim));
-        if (e != hipSuccess) return e;
-        d.base = sym;
-    }
-    *out = &d;
-    return hipSuccess;
-}
-
-hipError_t claim_slot(hipStream_t s, uint32_t** ctr, uint32_t** done) {
-    std::lock_guard<std::mutex> lock(g_claim_mutex);
-    ClaimDevice* d = nullptr;
-    hipError_t e = claim_device(&d);
-    if (e != hipSuccess) return e;
-    int slot = -1, lru = 0;
-    for (int i = 0; i < kClaimSlots; ++i) {
-        if (d->used[i] && d->stream[i] == s) {
-            slot = i;
-            break;
-        }
-        if (d->used[i] < d->used[lru]) lru = i;  // free slots (0) come first
-    }
-    if (slot < 0) {
-        slot = lru;
-        d->stream[slot] = s;
-    }
-    d->used[slot] = ++d->tick;
-    constexpr size_t per_slot = (size_t)kClaimGroups * kClaimStride;
-    *ctr = d->base + slot * per_slot;
-    *done = d->base + (kClaimSlots + slot) * per_slot;
-    return hipSuccess;
-}
-
 // ------------------------------------------------------------------ pack / unpack (quantize_functions.py:417-473)
 // 16 codes (16 bytes) in -> 8 bytes out per thread step; tail handled by a scalar loop.
 template <int BIAS>
@@ -307,19 +254,6 @@ extern "C" const char* nncf_amd_status_string(int st) {
         case NNCF_AMD_ERR_UNSUPPORTED: return "unsupported request";
         default: return "unknown status";
     }
-}
-
-extern "C" int nncf_amd_reset_claims(void* stream) {
-    std::lock_guard<std::mutex> lock(g_claim_mutex);
-    ClaimDevice* d = nullptr;
-    hipError_t e = claim_device(&d);
-    if (e == hipSuccess) e = hipMemsetAsync(d->base, 0, sizeof(uint32_t) * 2 * kClaimSlots * kClaimGroups * kClaimStride,
-                                            (hipStream_t)stream);
-    if (e != hipSuccess) {
-        set_error("reset_claims: %s", hipGetErrorString(e));
-        return NNCF_AMD_ERR_LAUNCH;
-    }
-    return NNCF_AMD_OK;
 }
 
 extern "C" int nncf_amd_pack_u4(const uint8_t* in, int64_t n, uint8_t* out, void* stream) {

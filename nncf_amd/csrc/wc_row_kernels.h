@@ -1,11 +1,11 @@
 // wc_row_kernels.h -- multi-tensor per-channel lowering: the quantization group is a whole row of the weight
 // (INT8 per-channel, the reference's default mode; 4-bit with group_size = -1), too long for one wave tile.
 //
-// A team (one wave for rows up to 512 vectors, one 256-thread block above) owns one row at a time, claimed from
-// the same counters as the tile kernel (wc_group_kernels.h).  The row is read ONCE, with non-temporal 16-byte
-// loads, and stays in registers (KEEP raw vectors per thread) between the min/max pass and the quantize pass;
-// what hides the load latency is occupancy (every resident wave has a whole row in flight), not a prefetch.
-// Codes leave as 8 bytes (or 4 bytes of nibbles) per lane and vector, streaming stores.
+// A team (one wave for rows up to 512 vectors, one 256-thread block above) owns ONE row.  The row is read once (LDS-DMA
+// for rows up to 32 KiB, non-temporal 16-byte loads above) and stays in registers (KEEP raw vectors per thread)
+// between the min/max pass and the quantize pass; what hides the load latency is occupancy (every resident team
+// has a whole row in flight).  Wave-owned rows come out of LDS so that a lane owns PAIRS of adjacent vectors and
+// its codes leave as 16-byte streaming stores.
 #pragma once
 #include "wc_group_kernels.h"
 
@@ -23,207 +23,12 @@ __device__ __forceinline__ Vec16 load16_nt(const Vec16* p) {
 
 // BatchArgs use: tile_start = prefix sums of ROWS, nfull[i] = vectors per row of tensor i, packed[i] = output
 // (1-byte codes or nibble-packed), scale[i], aux[i] = int32 zero points or NULL.
+// One row per team, a grid of rows / teams-per-block blocks: the workgroup dispatcher hands out the rows in address
+// order, occupancy hides the load latency (same finding as for the tile kernel, wc_group_kernels.h: 0.775 of the
+// HBM roofline for Llama-3-8B INT8_ASYM; a resident set of teams claiming rows from atomic counters and
+// prefetching the next row stopped at 0.68).
 template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED>
 __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
-    constexpr int E = Elem<DT>::kPerVec;
-    __shared__ float lds[kPolicyLds];
-    __shared__ typename Policy::Stat wave_stat[2][4];  // block teams: per-wave statistics, double-buffered
-    __shared__ uint32_t claim_sh[2];                    // block teams: the claimed row, double-buffered
-    int parity = 0;
-    // rows are staged by LDS-DMA: the next row lands in LDS while this one is processed from registers
-    // (wave-owned rows: a private image per wave; block-owned rows up to 32 KiB: one image per block)
-    constexpr bool DMA = TEAM == 64 || KEEP <= 8;
-    __shared__ Vec16 stage[TEAM == 64 ? 4 : 1][DMA ? TEAM * KEEP : 1];
-    Policy::init_shared(lds);
-    __syncthreads();
-    GroupArgs o = {};
-    o.mode = b.mode;
-    const Policy pol(o, lds);
-    const int lane = threadIdx.x & 63;
-    const int tl = threadIdx.x % TEAM;  // thread inside the team
-    const uint32_t total = b.tile_start[b.n];
-    const uint32_t part = (blockIdx.x >> 3) & ((1u << b.log2_groups) - 1);
-    const uint32_t lo = b.part_lo[part], hi = b.part_lo[part + 1];
-    (void)lo;
-    (void)total;
-    uint32_t* ctr = b.ctr + part * kClaimStride;
-    uint32_t* done = b.done + part * kClaimStride;
-    const uint32_t cbase = lo;
-    // team-uniform claim: a wave claims for itself, a block through thread 0 and LDS
-    claim_init();
-    auto claim_issue = [&]() {
-        if (TEAM == 64 ? lane == 0 : threadIdx.x == 0) claim_async(ctr);
-    };
-    auto claim_take = [&]() -> uint32_t {  // after the caller's vmcnt(0)
-        if constexpr (TEAM == 64) {
-            return cbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_value());
-        } else {
-            // one barrier: the slot is rewritten two rounds later, with the statistics barrier in between
-            if (threadIdx.x == 0) claim_sh[parity] = claim_value();
-            __syncthreads();
-            return cbase + claim_sh[parity];
-        }
-    };
-    // The claim of the next row is always in flight while this one is processed.  Block-owned rows are loaded
-    // straight into registers afterwards (a second register set for prefetching costs more in occupancy than it
-    // gains: measured); wave-owned rows (<= 8 KiB) are prefetched through LDS instead.
-    struct Row {
-        uint32_t vpr;
-        uint64_t row;
-        int i;
-    };
-    int scan = 0;
-    auto locate = [&](uint32_t r) {
-        while (r >= b.tile_start[scan + 1]) ++scan;
-        Row d;
-        d.i = scan;
-        d.vpr = b.nfull[scan];
-        d.row = r - b.tile_start[scan];
-        return d;
-    };
-    auto load_row = [&](const Row& d, Vec16* dst) {
-        const Vec16* src = (const Vec16*)b.w[d.i] + d.row * d.vpr;
-#pragma unroll
-        for (int k = 0; k < KEEP; ++k) {
-            const uint32_t j = tl + k * TEAM;
-            if (j < d.vpr) dst[k] = load16_nt(src + j);
-        }
-    };
-    // vector owned by this thread in register k.  Block-owned rows: tl + k * TEAM (what the coalesced register
-    // loads give).  Wave-owned rows come out of LDS, so a lane can own PAIRS of adjacent vectors: its codes then
-    // leave as one 16-byte store per pair instead of two 8-byte ones.
-    constexpr bool PAIRS = DMA && KEEP >= 2;
-    auto vec_of = [&](int k) -> uint32_t {
-        return PAIRS ? (uint32_t)(2 * TEAM * (k >> 1) + 2 * tl + (k & 1)) : (uint32_t)(tl + k * TEAM);
-    };
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t lds_base = (uint32_t)(uintptr_t)stage[TEAM == 64 ? wave : 0];  // (unused without DMA)
-    auto issue_dma = [&](const Row& d) {  // every wave brings its 64-vector slices of the team's image
-        const char* tbase = (const char*)b.w[d.i] + d.row * d.vpr * 16;  // wave-uniform
-        const uint32_t last = (d.vpr - 1) * 16u;
-        const uint32_t w0 = TEAM == 64 ? 0u : (uint32_t)wave * 64u;
-#pragma unroll
-        for (int u = 0; u < KEEP; ++u) {
-            const uint32_t v = (uint32_t)(u * TEAM) + w0;  // first vector of this instruction
-            const uint32_t off = (v + lane) * 16u;
-            dma16_nt(tbase, off < last ? off : last, lds_base + v * 16u);
-        }
-    };
-    claim_issue();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t r = claim_take();
-    parity ^= 1;  // (block teams) the slot just read must not be rewritten before everybody has read it
-    if (r >= hi) {  // (a team makes exactly one failing claim, the last thing it does with the counter)
-        if (TEAM == 64 ? lane == 0 : threadIdx.x == 0) claim_done(ctr, done, b.teams_on[part]);
-        return;
-    }
-    Row cd = locate(r), nd = cd;
-    Vec16 cur[KEEP];
-    if constexpr (DMA) issue_dma(cd);
-    else load_row(cd, cur);
-    claim_issue();
-    for (;;) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t rn = claim_take();  // (block teams: contains the barrier after which the whole image has landed)
-        if constexpr (DMA) {
-#pragma unroll
-            for (int k = 0; k < KEEP; ++k) cur[k] = stage[TEAM == 64 ? wave : 0][vec_of(k)];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (TEAM == 64) {
-                if (rn < hi) {
-                    nd = locate(rn);
-                    issue_dma(nd);
-                    claim_issue();
-                }
-            }
-        }
-        typename Policy::Stat st = pol.stat_init();
-#pragma unroll
-        for (int k = 0; k < KEEP; ++k) {
-            const uint32_t j = vec_of(k);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j < cd.vpr) {
-                float f[E];
-                unpack<DT>(cur[k], f);
-                pol.template stat_add_vec<E>(st, f);
-            }
-        }
-        pol.template stat_lanes<64>(st);
-        if constexpr (TEAM != 64) {
-            if (lane == 0) wave_stat[parity][wave] = st;
-            __syncthreads();  // also: everybody has copied the LDS image to registers, it may be overwritten
-            st = wave_stat[parity][0];
-#pragma unroll
-            for (int q = 1; q < 4; ++q) pol.stat_merge(st, wave_stat[parity][q]);
-            parity ^= 1;
-            if constexpr (DMA) {
-                if (rn < hi) {
-                    nd = locate(rn);
-                    issue_dma(nd);
-                    claim_issue();
-                }
-            }
-        }
-        const typename Policy::Par par = pol.compute(st);
-        o.scale_out = b.scale[cd.i];
-        o.zp_out = (int32_t*)b.aux[cd.i];
-        if (tl == 0) pol.template store<true>(o, (int64_t)cd.row, par);
-        if constexpr (PACKED) o.packed = b.packed[cd.i];
-        else o.codes = b.packed[cd.i];
-        // second unpack of the raw vectors (opaque, or the compiler keeps all KEEP*E floats of the first one
-        // alive across the reduction) and one vector at a time (no interleaving: registers are what buys occupancy)
-        auto opaque = [](Vec16 raw) {
-            asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));
-            return raw;
-        };
-        if constexpr (PAIRS) {
-#pragma unroll
-            for (int k = 0; k < KEEP; k += 2) {
-                const uint32_t j = vec_of(k);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + 1 < cd.vpr) {
-                    float f[2 * E];
-                    unpack<DT>(opaque(cur[k]), f);
-                    unpack<DT>(opaque(cur[k + 1]), f + E);
-                    pol.template quant_n_div<2 * E>(par, f, f);
-                    pol.template store_codes<2 * E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
-                } else if (j < cd.vpr) {
-                    float f[E];
-                    unpack<DT>(opaque(cur[k]), f);
-                    pol.template quant_n_div<E>(par, f, f);
-                    pol.template store_codes<E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < KEEP; ++k) {
-                const uint32_t j = vec_of(k);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j < cd.vpr) {
-                    float f[E];
-                    unpack<DT>(opaque(cur[k]), f);
-                    pol.template quant_n_div<E>(par, f, f);
-                    pol.template store_codes<E, true>(o, f, (int64_t)((cd.row * cd.vpr + j) * E));
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (rn >= hi) break;
-        if constexpr (DMA) {
-            cd = nd;
-        } else {
-            cd = locate(rn);
-            load_row(cd, cur);
-            claim_issue();
-        }
-    }
-    if (TEAM == 64 ? lane == 0 : threadIdx.x == 0) claim_done(ctr, done, b.teams_on[part]);  // rn was the failing claim
-}
-
-// One row per team, one launch-wide grid: the workgroup dispatcher hands out the rows in address order, occupancy
-// hides the load latency (experimental alternative to the claimed kernel above, NNCF_AMD_ROW_ONCE=1).
-template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED>
-__global__ __launch_bounds__(256) void k_rows_once(BatchArgs b) {
     constexpr int E = Elem<DT>::kPerVec;
     constexpr int TPB = 256 / TEAM;
     __shared__ float lds[kPolicyLds];
@@ -358,31 +163,13 @@ static inline RowClass row_class(int64_t vpr) {
     return {0, 0};
 }
 
-constexpr int kRowBlocksPerCU = 0;  // 0: as many as fit (occupancy)
-
 template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED>
 static hipError_t launch_rows(BatchArgs& b, hipStream_t s) {
-    static const int per_cu = tile_knob("NNCF_AMD_ROW_BLOCKS_PER_CU", 1, 16, kRowBlocksPerCU);
-    static const int resident = resident_blocks(k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>, per_cu);
-    // Parts of the row range (sequential streams): as few as the claim counters allow -- measured on Llama-3-8B INT8
-    // (8 KiB and 28 KiB rows): 32 parts 0.63, 16: 0.66, 8: 0.68 of the roofline, 4: 0.52 (one address sustains ~10^8
-    // atomics/s) -- so the count follows the shortest row of the launch: ~6 x 10^7 claims/s per counter at the
-    // ~3.6 TB/s the rows are read with.
-    static const int forced = tile_knob("NNCF_AMD_ROW_CLAIM_GROUPS", 1, kClaimGroupsUsed, 0);
-    uint32_t min_vpr = 0xffffffffu;
-    for (int j = 0; j < b.n; ++j) min_vpr = b.nfull[j] < min_vpr ? b.nfull[j] : min_vpr;
-    int groups = 8;
-    while (groups < kClaimGroupsUsed && (double)groups * (double)min_vpr * 16.0 * 6e7 < 3.6e12) groups *= 2;
-    if (forced > 0 && (forced & (forced - 1)) == 0) groups = forced;
     constexpr int TPB = 256 / TEAM;
-    const int64_t blocks = ((int64_t)b.tile_start[b.n] + TPB - 1) / TPB;
-    static const int once = tile_knob("NNCF_AMD_ROW_ONCE", 0, 1, 0);
-    if (once) {
-        hipLaunchKernelGGL((k_rows_once<Policy, DT, TEAM, KEEP, PACKED>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-        return hipPeekAtLastError();
-    }
-    return launch_claimed(k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>, (int)(blocks < resident ? blocks : resident), TPB, b, s,
-                          1, groups);
+    const int64_t blocks = ((int64_t)b.tile_start[b.n] + TPB - 1) / TPB;  // rows <= 2^30 per launch
+    if (blocks > 0)
+        hipLaunchKernelGGL((k_rows_batch<Policy, DT, TEAM, KEEP, PACKED>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+    return hipPeekAtLastError();
 }
 
 template <typename Policy, int DT, bool PACKED>

@@ -121,28 +121,6 @@ int main(int argc, char** argv) {
         double usb = ms * 1e3 / 10;
         printf("batched x%d (HBM-cold): %.2f us  in %.1f GB/s  algorithmic %.1f GB/s (%.1f%% of 8 TB/s)\n", NB, usb,
                NB * n * 2.0 / usb * 1e-3, NB * alg / usb * 1e-3, NB * alg / usb * 1e-3 / 80.0);
-        if (getenv("WC_CLK")) {
-            const int nw = (getenv("WC_CLK_BLOCKS") ? atoi(getenv("WC_CLK_BLOCKS")) : 768) * 4;
-            std::vector<uint64_t> rec(nw * 8);
-            CK(hipMemcpy(rec.data(), ss[0], rec.size() * 8, hipMemcpyDeviceToHost));
-            uint64_t t0 = ~0ull, t1 = 0;
-            double tot = 0, tiles = 0, ph[4] = {0, 0, 0, 0};
-            for (int i = 0; i < nw; ++i) {
-                if (rec[8 * i] < t0) t0 = rec[8 * i];
-                if (rec[8 * i + 1] > t1) t1 = rec[8 * i + 1];
-                tot += rec[8 * i + 2]; tiles += rec[8 * i + 3];
-                for (int k = 0; k < 4; ++k) ph[k] += rec[8 * i + 4 + k];
-            }
-            printf("kernel span %.1f us; per tile: %.0f cycles = wait %.0f + lds %.0f + stores/dma %.0f + arithmetic %.0f (+ %.0f outside the loop)\n",
-                   (t1 - t0) * 0.01, tot / tiles, ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / tiles,
-                   (tot - ph[0] - ph[1] - ph[2] - ph[3]) / tiles);
-            FILE* fo = fopen(getenv("WC_CLK"), "w");
-            for (int i = 0; i < nw; ++i)
-                fprintf(fo, "%d %.2f %.2f %llu %llu %llu %llu %llu %llu\n", i, (rec[8 * i] - t0) * 0.01, (rec[8 * i + 1] - t0) * 0.01,
-                        (unsigned long long)rec[8 * i + 2], (unsigned long long)rec[8 * i + 3], (unsigned long long)rec[8 * i + 4],
-                        (unsigned long long)rec[8 * i + 5], (unsigned long long)rec[8 * i + 6], (unsigned long long)rec[8 * i + 7]);
-            fclose(fo);
-        }
         // probe over the same distinct buffers
         int64_t nvecb = n / 8;
         for (int grid : {2048, 8192}) {
