@@ -321,6 +321,42 @@ def test_batched_kernel_full_size_vs_oracle(mode, gs):
         _assert_cw_equals_oracle(cw, _oracle_packed(w, mode, gs), f"{mode} g{gs} {tuple(w.shape)}")
 
 
+@pytest.mark.parametrize("mode,gs", [("int4_sym", 128), ("int4_asym", 128), ("int4_asym", 32), ("int8_asym", -1),
+                                     ("int8_sym", -1), ("int4_sym", -1)])
+def test_exact_division_path_high_volume(mode, gs):
+    """The lowering kernels take their codes from a correctly rounded quotient built with fma corrections
+    (IntPolicyT::quant_n_div) instead of an IEEE divide.  8 M full-mantissa fp32 weights whose rows span magnitudes
+    2^-50 ... 2^50 (every quotient then lands near a rounding boundary of its own), rows beyond the fast range
+    (2^-70, 2^70: the IEEE-divide branch), negative-scale groups (largest element positive), denormal and constant
+    rows: codes, scales and zero points bit-exact against the oracle."""
+    from nncf_amd import weight_lowering as wl
+    rng = np.random.default_rng(2024)
+    rows, cols = 2048, 4096
+    w = rng.standard_normal((rows, cols)).astype(np.float32)
+    # exact ties and near-ties on a quarter of the rows: multiples of half the scale, nudged by one ulp
+    half = (rng.integers(-16, 16, (rows // 4, cols)).astype(np.float32) + 0.5) * np.float32(0.37)
+    half[:, 0] = np.float32(-8 * 0.37)
+    half[:, 1::9] = np.nextafter(half[:, 1::9], np.float32(np.inf))
+    half[:, 2::9] = np.nextafter(half[:, 2::9], np.float32(-np.inf))
+    w[: rows // 4] = half
+    mag = np.exp2(rng.integers(-50, 51, (rows, 1))).astype(np.float32)
+    mag[5], mag[6], mag[7], mag[8] = 2.0 ** -70, 2.0 ** 70, 2.0 ** -100, 2.0 ** 100
+    w = (w * mag).astype(np.float32)
+    w[9] = np.abs(w[9])                    # all positive: negative scale in the symmetric modes
+    w[10] = 1e-42                          # denormal constant row
+    w[11] = -3.25                          # constant row
+    w[12, ::2] = 0.0
+    ws = [to_dev(w[:1024], "f32"), to_dev(w[1024:], "f32")]
+    got = wl.compress_weights_packed_batched(ws, _cfg(mode, gs))
+    for part, cw in zip((w[:1024], w[1024:]), got):
+        rc, rs, rz = O.compress_weight(part, (1,), mode, gs)
+        ref = O.pack_uint4(rc) if mode == "int4_asym" else O.pack_int4(rc) if mode == "int4_sym" else rc
+        assert_equal_nan(host(cw.scale).reshape(rs.shape), rs, f"{mode} g{gs} scale")
+        if rz is not None:
+            assert_equal_nan(host(cw.zero_point).reshape(rz.shape), rz, f"{mode} g{gs} zp")
+        assert_equal_nan(host(cw.tensor).reshape(ref.shape), ref, f"{mode} g{gs} codes")
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("mode", ["int8_asym", "int8_sym", "int4_sym", "int4_asym"])
 def test_per_channel_row_kernel_all_classes(mode, dtype):
