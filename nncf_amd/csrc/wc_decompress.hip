@@ -94,6 +94,117 @@ __global__ __launch_bounds__(256) void k_decompress8(const uint8_t* __restrict__
     store8<OUT_DT>(out, e0, r);
 }
 
+// The modules' own configurations (fp16 scale: INT8 / INT4 sym / asym, NF4; E8M0 scale: MXFP4), mode and output
+// dtype fixed at compile time.  The generic kernel above spends ~12 VALU slots per element (a 64-bit division per
+// thread, conversions through fp32, a constant-memory table for NF4) and is issue-bound at 3.2-4.5 TB/s; here
+//   * the arithmetic of the fp16 configurations is packed fp16 on exact operands -- an integer code c enters as the
+//     fp16 number 1024 + c (its bits OR-ed under the exponent 0x6400), d = (1024 + c) - (1024 + z) is exact and
+//     RN_fp16(d * s) is what `v_pk_mul_f16` returns (the reference multiplies in fp16 as well) -- two elements per
+//     issue slot and no conversion on the way in;
+//   * e2m1 codes enter as the fp16 number value * 2^-14 (exponent and mantissa bits shifted into place, zero and
+//     the subnormal 0.5 included), the factor goes into the power-of-two scale;
+//   * NF4 reads a 16-entry fp16 table in LDS;
+//   * the group of a thread's 8 elements comes from a 2-D grid: blockIdx.y counts spans of `span_groups` groups, and
+//     inside a span (< 2^24 vectors) the division is a shift or a float multiply with one correction.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+template <int MODE, int OUT_DT>
+__global__ __launch_bounds__(256) void k_decompress_h(const uint8_t* __restrict__ codes, const void* __restrict__ scale,
+                                                      const uint8_t* __restrict__ zp, void* __restrict__ out, uint64_t n_vec,
+                                                      uint32_t d, uint32_t span_groups, float rcp_d, int shift) {
+    __shared__ _Float16 lut[16];
+    if constexpr (MODE == NNCF_AMD_NF4) {
+        if (threadIdx.x < 16) lut[threadIdx.x] = (_Float16)kNF4Q[threadIdx.x];
+        __syncthreads();
+    }
+    const uint32_t vl = blockIdx.x * 256 + threadIdx.x;  // vector of 8 elements inside the span
+    const uint32_t span_vec = span_groups * d;
+    uint32_t gl;
+    if (shift >= 0) {
+        gl = vl >> shift;
+    } else {
+        gl = (uint32_t)((float)vl * rcp_d);  // within 1 of vl / d (vl < 2^24)
+        const uint32_t r = vl - gl * d;
+        if ((int32_t)r < 0) --gl;
+        else if (r >= d) ++gl;
+    }
+    const uint64_t v = (uint64_t)blockIdx.y * span_vec + vl;
+    if (vl >= span_vec || v >= n_vec) return;
+    const uint64_t g = (uint64_t)blockIdx.y * span_groups + gl;
+    const uint64_t e0 = v * 8;
+    float r[8];
+    if constexpr (MODE == NNCF_AMD_MXFP4) {
+        // scale 2^(byte - 127) times the 2^14 of the code's fp16 image; byte 0 stays the zero it is in k_decompress8
+        const uint32_t byte = ((const uint8_t*)scale)[g];
+        const float s = __builtin_bit_cast(float, byte << 23) * 16384.0f;
+        const uint32_t p = *(const uint32_t*)(codes + e0 / 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t q = p >> (4 * k);
+            const h2 h = __builtin_bit_cast(h2, ((q & 0x00070007u) << 9) | ((q & 0x00080008u) << 12));
+            r[k] = (float)h.x * s;
+            r[k + 4] = (float)h.y * s;
+        }
+    } else {
+        const _Float16 s = __builtin_bit_cast(_Float16, ((const uint16_t*)scale)[g]);
+        const h2 s2 = {s, s};
+        h2 h[4];
+        if constexpr (MODE == NNCF_AMD_NF4) {
+            const uint32_t p = *(const uint32_t*)(codes + e0 / 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const h2 q = {lut[(p >> (8 * k)) & 15], lut[(p >> (8 * k + 4)) & 15]};
+                h[k] = q * s2;  // elements 2k, 2k + 1
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[2 * k] = (float)h[k].x;
+                r[2 * k + 1] = (float)h[k].y;
+            }
+        } else if constexpr (MODE == NNCF_AMD_INT4_SYM || MODE == NNCF_AMD_INT4_ASYM) {
+            const uint32_t p = *(const uint32_t*)(codes + e0 / 2);
+            uint32_t z = 8;  // INT4_SYM: codes are stored with a +8 bias (pack_int4)
+            if constexpr (MODE == NNCF_AMD_INT4_ASYM) z = (zp[g >> 1] >> (4 * (g & 1))) & 15;
+            const _Float16 zb = __builtin_bit_cast(_Float16, (uint16_t)(0x6400u | z));
+            const h2 zb2 = {zb, zb};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const h2 c = __builtin_bit_cast(h2, ((p >> (4 * k)) & 0x000f000fu) | 0x64006400u);  // elements k, k + 4
+                h[k] = (c - zb2) * s2;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[k] = (float)h[k].x;
+                r[k + 4] = (float)h[k].y;
+            }
+        } else {
+            const uint2 pp = *(const uint2*)(codes + e0);
+            uint32_t w[2] = {pp.x, pp.y};
+            uint32_t z = 128;  // INT8_SYM: the sign bit is flipped, code + 128
+            if constexpr (MODE == NNCF_AMD_INT8_ASYM) z = zp[g];
+            else {
+                w[0] ^= 0x80808080u;
+                w[1] ^= 0x80808080u;
+            }
+            const _Float16 zb = __builtin_bit_cast(_Float16, (uint16_t)(0x6400u | z));
+            const h2 zb2 = {zb, zb};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // bytes (2k & 3), (2k & 3) + 1 of dword k / 2 under the exponent byte 0x64: elements 2k, 2k + 1
+                const uint32_t sel = (k & 1) ? 0x03070106u : 0x03050104u;
+                const h2 c = __builtin_bit_cast(h2, __builtin_amdgcn_perm(w[k >> 1], 0x64006400u, sel));
+                h[k] = (c - zb2) * s2;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[2 * k] = (float)h[k].x;
+                r[2 * k + 1] = (float)h[k].y;
+            }
+        }
+    }
+    store8<OUT_DT>(out, (int64_t)e0, r);
+}
+
 // any group size / alignment: one thread per element (correctness path)
 template <int OUT_DT>
 __global__ __launch_bounds__(256) void k_decompress1(const uint8_t* __restrict__ codes, int mode, int64_t n_elems, int64_t gs,
@@ -155,8 +266,46 @@ extern "C" int nncf_amd_decompress(const uint8_t* codes, int mode, int64_t n_gro
     if (n_groups == 0) return NNCF_AMD_OK;
     const int64_t n = n_groups * group_size;
     const bool fast = group_size % 8 == 0 && (((uintptr_t)codes | (uintptr_t)out) & 15u) == 0;
-    const dim3 grid((unsigned)(((fast ? n / 8 : n) + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
+    const bool half_cfg = scale_kind == kScaleF16 && (mode <= NNCF_AMD_INT4_SYM || mode == NNCF_AMD_NF4);
+    if (fast && (half_cfg || (mode == NNCF_AMD_MXFP4 && scale_kind == kScaleE8M0))) {
+        const uint64_t n_vec = (uint64_t)n / 8;
+        const uint64_t d = (uint64_t)group_size / 8;                    // vectors per group
+        const uint64_t span_groups = d >= 4096 ? 1 : 4096 / d;           // >= 4096 vectors (16 blocks) per span
+        const uint64_t spans = ((uint64_t)n_groups + span_groups - 1) / span_groups;
+        if (d < ((uint64_t)1 << 23) && spans <= 65535) {
+            int shift = -1;
+            if ((d & (d - 1)) == 0) {
+                shift = 0;
+                while (((uint64_t)1 << shift) < d) ++shift;
+            }
+            const dim3 grid((unsigned)((span_groups * d + 255) / 256), (unsigned)spans);
+#define LAUNCH_H(M, DT)                                                                                                     \
+    hipLaunchKernelGGL((k_decompress_h<M, DT>), grid, dim3(256), 0, s, codes, scale, zero_point, out, n_vec, (uint32_t)d,  \
+                       (uint32_t)span_groups, 1.0f / (float)d, shift)
+#define LAUNCH_HM(DT)                                                                                                       \
+    switch (mode) {                                                                                                         \
+        case NNCF_AMD_INT8_ASYM: LAUNCH_H(NNCF_AMD_INT8_ASYM, DT); break;                                                    \
+        case NNCF_AMD_INT8_SYM: LAUNCH_H(NNCF_AMD_INT8_SYM, DT); break;                                                      \
+        case NNCF_AMD_INT4_ASYM: LAUNCH_H(NNCF_AMD_INT4_ASYM, DT); break;                                                    \
+        case NNCF_AMD_INT4_SYM: LAUNCH_H(NNCF_AMD_INT4_SYM, DT); break;                                                      \
+        case NNCF_AMD_NF4: LAUNCH_H(NNCF_AMD_NF4, DT); break;                                                                \
+        default: LAUNCH_H(NNCF_AMD_MXFP4, DT); break;                                                                        \
+    }
+            switch (out_dtype) {
+                case NNCF_AMD_F32: LAUNCH_HM(NNCF_AMD_F32); break;
+                case NNCF_AMD_F16: LAUNCH_HM(NNCF_AMD_F16); break;
+                case NNCF_AMD_BF16: LAUNCH_HM(NNCF_AMD_BF16); break;
+                default:
+                    set_error("decompress: unsupported output dtype %d", out_dtype);
+                    return NNCF_AMD_ERR_DTYPE;
+            }
+#undef LAUNCH_HM
+#undef LAUNCH_H
+            return launch_status("decompress");
+        }
+    }
+    const dim3 grid((unsigned)(((fast ? n / 8 : n) + 255) / 256));
 #define LAUNCH(DT)                                                                                                         \
     if (fast)                                                                                                              \
         hipLaunchKernelGGL((k_decompress8<DT>), grid, dim3(256), 0, s, codes, mode, n, group_size, scale, scale_kind,     \
