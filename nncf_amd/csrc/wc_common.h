@@ -38,6 +38,19 @@ struct OncePerDevice {
     }
 };
 
+// Batched error metric (wc_misc.hip: entry point and the row-per-block kernels; wc_int_err.hip: the tile kernel)
+constexpr int kErrBatch = 48;
+struct ErrBatchArgs {
+    int n, mode, reduction;
+    int64_t gs;                         // -1: the whole row
+    uint32_t row_start[kErrBatch + 1];  // prefix sums of the row counts
+    uint32_t cols[kErrBatch];
+    const void* w[kErrBatch];
+};
+// Launches the tile kernel over the rows of `a` when its shape conditions hold (returns false otherwise, nothing
+// launched): ws[global row] = sum of squared quantization errors of the row.
+bool err_tiles_launch(int w_dtype, const ErrBatchArgs& a, float* ws, hipStream_t s);
+
 // ---------------------------------------------------------------- 16-byte vectors of the input dtype
 struct alignas(16) Vec16 {
     uint32_t w[4];

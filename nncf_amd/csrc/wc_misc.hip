@@ -178,14 +178,6 @@ __global__ __launch_bounds__(256) void k_err_final(const float* ws, int64_t chan
 // (the mixed-precision scoring loop, mixed_precision.py:161-199, walks the weights one by one).  2-D [rows, cols]
 // weights reduced along the columns.  Pass 1: one block per row of any tensor -> ws[global row]; pass 2: one block per
 // tensor -> results[i].
-constexpr int kErrBatch = 48;
-struct ErrBatchArgs {
-    int n, mode, reduction;
-    int64_t gs;                         // -1: the whole row
-    uint32_t row_start[kErrBatch + 1];  // prefix sums of the row counts
-    uint32_t cols[kErrBatch];
-    const void* w[kErrBatch];
-};
 
 template <int DT>
 __global__ __launch_bounds__(256) void k_err_rows_batch(ErrBatchArgs a, float* ws) {
@@ -467,6 +459,8 @@ extern "C" int nncf_amd_int_quant_error_batched(int n, const void* const* weight
         a.row_start[j] = (uint32_t)acc;
         a.n = j;
         const dim3 grid((unsigned)acc);
+        if (err_tiles_launch(w_dtype, a, ws, s)) {  // grouped modes on 16-byte rows: the tile kernel (wc_int_err.hip)
+        } else
         switch (w_dtype) {
             case NNCF_AMD_F32: hipLaunchKernelGGL((k_err_rows_batch<NNCF_AMD_F32>), grid, dim3(256), 0, s, a, ws); break;
             case NNCF_AMD_F16: hipLaunchKernelGGL((k_err_rows_batch<NNCF_AMD_F16>), grid, dim3(256), 0, s, a, ws); break;

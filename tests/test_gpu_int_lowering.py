@@ -386,11 +386,14 @@ def test_per_channel_row_kernel_all_classes(mode, dtype):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("reduction", ["max_mean", "frobenius"])
-@pytest.mark.parametrize("mode,gs", [("int8_asym", -1), ("int4_sym", 64), ("int4_asym", -1)])
+@pytest.mark.parametrize("mode,gs", [("int8_asym", -1), ("int4_sym", 64), ("int4_asym", -1), ("int4_asym", 128),
+                                     ("int8_sym", 32), ("int4_sym", 16)])
 def test_batched_error_metric_vs_oracle_and_single(mode, gs, reduction, dtype):
     """nncf_amd_int_quant_error_batched (one pair of launches for many weights, what the mixed-precision scoring
     uses) against the oracle's get_integer_quantization_error (rtol 1e-4: the reference's own tolerance for this
-    reduction) and bit-equal to the per-weight entry point; > 48 tensors = several launches."""
+    reduction) and equal to the per-weight entry point up to the order of the fp32 sums (the batched path takes the
+    tile kernel for grouped modes on 64-byte rows, the per-weight path a block per channel); > 48 tensors = several
+    launches."""
     from nncf_amd import weight_lowering as wl
     rng = np.random.default_rng(5)
     shapes = [(7, 256), (64, 1024), (300, 512), (1, 64), (33, 4096)] * 11  # 55 tensors
@@ -401,7 +404,7 @@ def test_batched_error_metric_vs_oracle_and_single(mode, gs, reduction, dtype):
     got = wl.get_integer_quantization_errors(ws, [(1,)] * len(ws), cfg, reduction)
     assert len(got) == len(ws)
     for i in range(0, len(ws), 4):
-        assert got[i] == wl.get_integer_quantization_error(ws[i], (1,), cfg, reduction)
+        np.testing.assert_allclose(got[i], wl.get_integer_quantization_error(ws[i], (1,), cfg, reduction), rtol=2e-6, atol=1e-12)
         ref = O.get_integer_quantization_error(ws32[i], (1,), mode, gs, reduction)
         np.testing.assert_allclose(got[i], ref, rtol=1e-4, atol=1e-12)
     from nncf_amd import errors
