@@ -649,8 +649,13 @@ class WeightCompression:
                                                       want_e8m0=cfg.mode == CompressWeightsMode.MXFP4)
             for wp, cw in zip(wps, outs):
                 results[wp.weight_name] = cw
+        owners: Dict[int, List[nn.Module]] = {}  # weight parameter -> the modules that hold it (tied weights: several)
+        for mod in self._model.modules():
+            w = getattr(mod, "_parameters", {}).get("weight")
+            if w is not None:
+                owners.setdefault(id(w), []).append(mod)
         for wp in all_params:
-            insert_decompressor(self._model, wp, results[wp.weight_name])
+            insert_decompressor(self._model, wp, results[wp.weight_name], owners)
 
     def _statistics_tag(self) -> str:
         """What a statistics cache file must have been collected for to be reusable."""
@@ -740,16 +745,22 @@ def make_decompressor(cfg: WeightCompressionConfig, cw: CompressedWeight, weight
     raise InternalError(f"no decompressor for {mode}")
 
 
-def insert_decompressor(model: nn.Module, wp: WeightCompressionParameters, cw: CompressedWeight) -> None:
+def insert_decompressor(model: nn.Module, wp: WeightCompressionParameters, cw: CompressedWeight,
+                        owners: Optional[Dict[int, List[nn.Module]]] = None) -> None:
     """torch_backend.py:403-422: the packed tensor becomes the module's parameter, the decompressor runs on every
-    read of it.  Modules that share the parameter (tied embeddings) share the packed tensor and the decompressor."""
+    read of it.  Modules that share the parameter (tied embeddings) share the packed tensor and the decompressor.
+    `owners`: id(weight parameter) -> modules holding it, built once by the caller (one walk over the model
+    instead of one per weight)."""
     decompressor = make_decompressor(wp.compression_config, cw, wp.weight_shape, wp.weight_dtype)
     old = wp.module.weight
     packed = nn.Parameter(cw.tensor, requires_grad=False)
-    for mod in model.modules():
-        if getattr(mod, "_parameters", None) and mod._parameters.get("weight") is old:
-            mod.weight = packed
-            parametrize.register_parametrization(mod, "weight", decompressor, unsafe=True)
+    if owners is not None:
+        mods = owners.get(id(old), [])
+    else:
+        mods = [m for m in model.modules() if getattr(m, "_parameters", None) and m._parameters.get("weight") is old]
+    for mod in mods:
+        mod.weight = packed
+        parametrize.register_parametrization(mod, "weight", decompressor, unsafe=True)
 
 
 # ------------------------------------------------------------------------------------------------------ public
