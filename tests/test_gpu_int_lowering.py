@@ -386,7 +386,7 @@ def test_per_channel_row_kernel_all_classes(mode, dtype):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("reduction", ["max_mean", "frobenius"])
-@pytest.mark.parametrize("mode,gs", [("int8_asym", -1), ("int4_sym", 64), ("int4_asym", -1), ("int4_asym", 128),
+@pytest.mark.parametrize("mode,gs", [("int8_asym", -1), ("int4_sym", 64), ("int4_asym", -1), ("int4_asym", 32),
                                      ("int8_sym", 32), ("int4_sym", 16)])
 def test_batched_error_metric_vs_oracle_and_single(mode, gs, reduction, dtype):
     """nncf_amd_int_quant_error_batched (one pair of launches for many weights, what the mixed-precision scoring
