@@ -165,7 +165,7 @@ struct FloatPolicy {
             }
         }
     }
-    template <int NE, int GPL, bool NT>
+    template <int NE, int GPL, bool NT, bool DIV = false>
     __device__ __forceinline__ void emit_lane(const GroupArgs& a, const Par* par, float* f, int64_t e0) const {
         constexpr int SG = NE / GPL;
         int code[NE];

@@ -108,11 +108,12 @@ __device__ __forceinline__ void emit_vec(const GroupArgs& a, const Policy& pol, 
 //   the XOR spreads the 16 lanes that one ds_read_b128 services together over all 64 banks (conflict free).
 //   The DMA writes slots linearly (slot = u*64 + lane), so the permutation is applied to the global SOURCE
 //   address; one DMA instruction still reads one contiguous KiB.
-// LEAN: compile-time promise that only packed codes + computed parameters are written (the data-free
-// compress path): no uniform output branches.
+// One tile per wave, a grid of tiles/4 blocks (see the multi-tensor kernel below for why).
+// GIVEN: the group parameters come from the caller (scale_in [, zp_in]); otherwise they are computed from the tile and
+// the codes may take the correctly-rounded-quotient path (Policy::emit_lane<..., DIV = true>).
 constexpr int kVPL = 4;
 
-template <typename Policy, int DT, int VPG, bool LEAN>
+template <typename Policy, int DT, int VPG, bool GIVEN>
 __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
     constexpr int VPL = kVPL;
     constexpr int E = Elem<DT>::kPerVec;
@@ -124,87 +125,59 @@ __global__ __launch_bounds__(256) void k_grouped(GroupArgs a) {
     static_assert(LPG <= 64, "group must fit in one wave");
     __shared__ Vec16 stage[4][TILE];
     __shared__ __align__(16) float lds[kPolicyLds];
-    Policy::init_shared(lds);
-    __syncthreads();
-    const Policy pol(a, lds);
-    GroupArgs o = a;
-    if constexpr (LEAN) {
-        o.codes = nullptr;
-        o.values = nullptr;
-        o.dq = nullptr;
-        o.scale_in = nullptr;
-    }
     const int64_t nvec = a.n_groups * VPG;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile bases stay in SGPRs
     Vec16* my = stage[wave];
-    const char* __restrict__ wbytes = (const char*)a.w;
-    const int64_t n_tiles = (nvec + TILE - 1) / TILE;
-    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t wave_count = (int64_t)gridDim.x * 4;
-    // source permutation of the DMA (see above): slot s = u*64 + lane holds vector (l = s>>2, k = (s&3)^((s>>4)&3))
-    uint32_t src_off[VPL];  // byte offset inside the tile
+    const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * TILE;  // first vector of this wave's tile
+    const bool have = base < nvec;
+    if (have) {
+        // source permutation of the DMA (see above): slot s = u*64 + lane holds vector (l = s>>2, k = (s&3)^((s>>4)&3))
+        const char* tbase = (const char*)a.w + base * 16;  // wave-uniform
+        const uint32_t last = base + TILE <= nvec ? 0xffffffffu : (uint32_t)(nvec - base - 1) * 16u;  // partial tile: clamp
 #pragma unroll
-    for (int u = 0; u < VPL; ++u) {
-        const int sidx = u * 64 + lane;
-        src_off[u] = (uint32_t)((sidx & ~3) + ((sidx & 3) ^ ((sidx >> 4) & 3))) * 16u;
+        for (int u = 0; u < VPL; ++u) {
+            const int sidx = u * 64 + lane;
+            const uint32_t off = (uint32_t)((sidx & ~3) + ((sidx & 3) ^ ((sidx >> 4) & 3))) * 16u;
+            const uint32_t o2 = off < last ? off : last;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + o2),
+                                             (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
+        }
     }
+    Policy::init_shared(lds);
+    __syncthreads();
+    if (!have) return;
+    const Policy pol(a, lds);
     const int rot = (lane >> 2) & 3;
-    auto issue_dma = [&](int64_t tile) {
-        const int64_t base = tile * TILE;
-        const char* tbase = wbytes + base * 16;  // wave-uniform
-        if (base + TILE <= nvec) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float f[NE];
 #pragma unroll
-            for (int u = 0; u < VPL; ++u)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + src_off[u]),
-                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
-        } else {
-            const uint32_t last = (uint32_t)(nvec - base - 1) * 16u;  // partial tile: clamp to the last valid vector
+    for (int k = 0; k < VPL; ++k) {
+        const Vec16 raw = my[lane * VPL + (k ^ rot)];
+        unpack<DT>(raw, f + k * E);
+    }
+    const int64_t v0 = base + (int64_t)lane * VPL;  // first vector of this lane
+    const bool live = v0 < nvec;                    // host guarantees nvec % VPL == 0: lanes are all-or-nothing
+    const int64_t g0 = v0 / VPG;
+    typename Policy::Par par[GPL];
+    if constexpr (!GIVEN) {
 #pragma unroll
-            for (int u = 0; u < VPL; ++u) {
-                const uint32_t off = src_off[u] < last ? src_off[u] : last;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + off),
-                                                 (__attribute__((address_space(3))) void*)(my + u * 64), 16, 0, 0);
-            }
+        for (int gi = 0; gi < GPL; ++gi) {
+            typename Policy::Stat st = pol.stat_init();
+            pol.template stat_add_vec<SG>(st, f + gi * SG);
+            if constexpr (LPG > 1) pol.template stat_lanes<LPG>(st);  // all 64 lanes take part
+            par[gi] = pol.compute(st);
         }
-    };
-    int64_t tile = wave_global;
-    if (tile < n_tiles) issue_dma(tile);
-    for (; tile < n_tiles; tile += wave_count) {
-        const int64_t base = tile * TILE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float f[NE];
+    } else {
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) {
-            const Vec16 raw = my[lane * VPL + (k ^ rot)];
-            unpack<DT>(raw, f + k * E);
+        for (int gi = 0; gi < GPL; ++gi) par[gi] = pol.load(a, live ? g0 + gi : 0);
+    }
+    if (live) {
+        if ((lane & (LPG - 1)) == 0) {
+#pragma unroll
+            for (int gi = 0; gi < GPL; ++gi) pol.template store<false>(a, g0 + gi, par[gi]);
         }
-        // the LDS image now lives in registers: refill it with this wave's next tile while this one is processed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tile + wave_count < n_tiles) issue_dma(tile + wave_count);
-        const int64_t v0 = base + (int64_t)lane * VPL;  // first vector of this lane
-        const bool live = v0 < nvec;                    // host guarantees nvec % VPL == 0: lanes are all-or-nothing
-        const int64_t g0 = v0 / VPG;
-        typename Policy::Par par[GPL];
-        if (LEAN || o.scale_in == nullptr) {
-#pragma unroll
-            for (int gi = 0; gi < GPL; ++gi) {
-                typename Policy::Stat st = pol.stat_init();
-                pol.template stat_add_vec<SG>(st, f + gi * SG);
-                if constexpr (LPG > 1) pol.template stat_lanes<LPG>(st);  // all 64 lanes take part
-                par[gi] = pol.compute(st);
-            }
-        } else {
-#pragma unroll
-            for (int gi = 0; gi < GPL; ++gi) par[gi] = pol.load(o, live ? g0 + gi : 0);
-        }
-        if (live) {
-            if ((lane & (LPG - 1)) == 0) {
-#pragma unroll
-                for (int gi = 0; gi < GPL; ++gi) pol.template store<false>(o, g0 + gi, par[gi]);
-            }
-            pol.template emit_lane<NE, GPL, false>(o, par, f, v0 * E);
-        }
+        pol.template emit_lane<NE, GPL, false, !GIVEN>(a, par, f, v0 * E);
     }
 }
 
@@ -573,9 +546,7 @@ template <typename Policy, int DT, int VPG>
 static void launch_grouped(const GroupArgs& a, hipStream_t s) {
     const int64_t nvec = a.n_groups * VPG;
     const int64_t tiles = (nvec + 64 * kVPL - 1) / (64 * kVPL);
-    // 256 CUs x 8 resident blocks; more tiles than that are strided over by the resident waves (k_grouped)
-    int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    const int64_t blocks = (tiles + 3) / 4;
     const bool lean = a.packed && a.scale_out && !a.scale_in && !a.codes && !a.values && !a.dq && nvec <= kMaxBatchVec;
     if (lean) {
         BatchArgs b = {};
@@ -583,6 +554,8 @@ static void launch_grouped(const GroupArgs& a, hipStream_t s) {
         b.mode = a.mode;
         batch_set(b, 0, 0, nvec, a.w, a.packed, a.scale_out, a.zp_out ? (void*)a.zp_out : (void*)a.e8m0_out);
         launch_batch<Policy, DT, VPG>(b, s);
+    } else if (a.scale_in) {
+        hipLaunchKernelGGL((k_grouped<Policy, DT, VPG, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     } else {
         hipLaunchKernelGGL((k_grouped<Policy, DT, VPG, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     }

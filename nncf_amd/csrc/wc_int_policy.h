@@ -295,11 +295,14 @@ struct IntPolicyT {
         for (int j = 0; j < NE / 8; ++j) out[j] = nibbles8(f + 8 * j);
     }
     // grouped kernel: NE consecutive elements of one lane, covering GPL whole groups (or a part of one)
-    template <int NE, int GPL, bool NT>
+    template <int NE, int GPL, bool NT, bool DIV = false>
     __device__ __forceinline__ void emit_lane(const GroupArgs& a, const Par* par, float* f, int64_t e0) const {
         constexpr int SG = NE / GPL;
 #pragma unroll
-        for (int gi = 0; gi < GPL; ++gi) quant_n<SG>(par[gi], f + gi * SG, f + gi * SG);  // in place
+        for (int gi = 0; gi < GPL; ++gi) {  // in place; DIV: the parameters were computed from these elements
+            if constexpr (DIV) quant_n_div<SG>(par[gi], f + gi * SG, f + gi * SG);
+            else quant_n<SG>(par[gi], f + gi * SG, f + gi * SG);
+        }
         store_codes<NE, NT>(a, f, e0);
 #pragma unroll
         for (int gi = 0; gi < GPL; ++gi) store_dq<SG>(a, par[gi], f + gi * SG, e0 + gi * SG);

@@ -374,6 +374,27 @@ extern "C" int nncf_amd_int_quant_error(const void* weight, int w_dtype, int64_t
     }
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
+    if (w_dtype != NNCF_AMD_F32 && w_dtype != NNCF_AMD_F16 && w_dtype != NNCF_AMD_BF16) {
+        set_error("int_quant_error: unsupported weight dtype %d", w_dtype);
+        return NNCF_AMD_ERR_DTYPE;
+    }
+    if (inner == 1 && r <= 0x7fffffff) {  // a [rows, cols] weight: the tile kernel when its shape conditions hold
+        ErrBatchArgs a = {};
+        a.n = 1;
+        a.mode = mode;
+        a.reduction = reduction;
+        a.gs = group_size;
+        a.row_start[0] = 0;
+        a.row_start[1] = (uint32_t)channels;
+        a.cols[0] = (uint32_t)r;
+        a.w[0] = weight;
+        if (err_tiles_launch(w_dtype, a, ws, s)) {
+            int st = launch_status("err_tiles");
+            if (st != NNCF_AMD_OK) return st;
+            hipLaunchKernelGGL(k_err_final, dim3(1), dim3(256), 0, s, (const float*)ws, channels, r, reduction, result);
+            return launch_status("err_final");
+        }
+    }
     switch (w_dtype) {
         case NNCF_AMD_F32:
             hipLaunchKernelGGL((k_err_channel<NNCF_AMD_F32>), dim3((unsigned)channels), dim3(256), 0, s, weight, r, inner, gs, mode, ws);
