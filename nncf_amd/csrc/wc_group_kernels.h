@@ -1,10 +1,12 @@
 // wc_group_kernels.h -- the three group-wise lowering kernel skeletons, shared by the integer
 // (wc_int_quant.hip) and float-codebook (wc_float_quant.hip) policies.
 //
-//   grouped : group = LPG consecutive lanes of one wave (LPG = group bytes / 16, power of two <= 64);
-//             16-byte coalesced loads, UNROLL KiB in flight per wave, DPP reductions, no LDS traffic.
+//   grouped : one 4-KiB tile per wave, staged through LDS by DMA so that a lane owns 64 contiguous bytes; a group is
+//             a power-of-two number of 16-byte vectors inside the tile (DPP reductions over its lanes).  Single-tensor
+//             form with any output mix (k_grouped) and multi-tensor packed form (k_grouped_batch).
 //   row     : group = one wave or one 256-thread block (long rows: per-channel INT8, fp32 g >= 512 ...);
-//             up to KEEP vectors per thread stay in registers between the statistics and quantize passes.
+//             up to KEEP vectors per thread stay in registers between the statistics and quantize passes
+//             (k_row here; the multi-tensor form is in wc_row_kernels.h).
 //   generic : one thread per group, any group size / inner stride / alignment (small or odd shapes).
 //
 // A Policy supplies the arithmetic:
@@ -16,6 +18,7 @@
 //   void quant(float w, const Par&, int& code, float& value)   scalar form (generic kernel)
 //   float dq(int code, float value, const Par&);  int nibble(int code)
 //   template<int E> void stat_add_vec(Stat&, const float*); template<int E> void emit(args, par, f, v)  vector forms
+//   emit_lane<NE, GPL, NT, DIV> / pack_lane<NE, GPL>: a lane's NE consecutive elements (tile kernels)
 #pragma once
 #include "wc_common.h"
 
