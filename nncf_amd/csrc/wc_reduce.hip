@@ -35,63 +35,98 @@ static inline int reduce_nsplit(int64_t batch, int64_t tokens, int64_t hidden) {
 }
 
 // partial layout: ws[((b * nsplit + s) * 3 + q) * hidden + k], q = 0: sum d, 1: sum d^2, 2: max |x|
-template <int DT, bool VEC>
-__global__ __launch_bounds__(64) void k_act_partials(const void* __restrict__ x, int64_t tokens, int64_t hidden, int nsplit,
-                                                      float* __restrict__ ws) {
+// SUB waves per block share one token slice (a quarter of its rows each, combined through LDS in wave order): a
+// single calibration sample ([1, 2048, 4096] bf16 = 16 MB) is 512 slices x column blocks, two waves per CU, and a
+// launch of it is three memory latencies long -- four times the waves, eight rows in flight per lane, same partials.
+// SUB = 1 (short inputs) is the single-wave form: per element the rows of a slice are summed in row order.
+template <int DT, bool VEC, int SUB>
+__global__ __launch_bounds__(64 * SUB) void k_act_partials(const void* __restrict__ x, int64_t tokens, int64_t hidden,
+                                                            int nsplit, float* __restrict__ ws) {
     constexpr int E = VEC ? Elem<DT>::kPerVec : 1;
-    const int64_t col0 = ((int64_t)blockIdx.x * 64 + threadIdx.x) * E;
-    if (col0 >= hidden) return;
+    constexpr int U = SUB > 1 ? 8 : 4;  // rows in flight per lane
+    __shared__ float part[SUB > 1 ? SUB - 1 : 1][3][E][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t col0 = ((int64_t)blockIdx.x * 64 + lane) * E;
+    const bool live = col0 < hidden;
     const int s = blockIdx.y;
     const int64_t b = blockIdx.z;
     const int64_t rows_per = (tokens + nsplit - 1) / nsplit;
-    const int64_t t0 = s * rows_per;
-    const int64_t t1 = t0 + rows_per < tokens ? t0 + rows_per : tokens;
+    int64_t t0 = s * rows_per;
+    int64_t t1 = t0 + rows_per < tokens ? t0 + rows_per : tokens;
+    if constexpr (SUB > 1) {
+        const int64_t rows_w = t1 > t0 ? (t1 - t0 + SUB - 1) / SUB : 0;
+        t0 += wv * rows_w;
+        t1 = t0 + rows_w < t1 ? t0 + rows_w : t1;
+    }
     const int64_t base = b * tokens * hidden;
     float x0[E], sd[E], sq[E], am[E];
-    if constexpr (VEC) {
-        unpack<DT>(*(const Vec16*)((const char*)x + (base + col0) * Elem<DT>::kBytes), x0);
-    } else {
-        x0[0] = Elem<DT>::load(x, base + col0);
-    }
 #pragma unroll
-    for (int i = 0; i < E; ++i) sd[i] = sq[i] = am[i] = 0.0f;
-    int64_t t = t0;
-    if constexpr (VEC) {
-        // 4 rows in flight per thread
-        for (; t + 4 <= t1; t += 4) {
-            Vec16 r[4];
+    for (int i = 0; i < E; ++i) x0[i] = sd[i] = sq[i] = am[i] = 0.0f;
+    if (live) {
+        if constexpr (VEC) {
+            unpack<DT>(*(const Vec16*)((const char*)x + (base + col0) * Elem<DT>::kBytes), x0);
+        } else {
+            x0[0] = Elem<DT>::load(x, base + col0);
+        }
+        int64_t t = t0;
+        if constexpr (VEC) {
+            for (; t + U <= t1; t += U) {
+                Vec16 r[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                r[u] = load16_stream((const char*)x + (base + (t + u) * hidden + col0) * Elem<DT>::kBytes);
+                for (int u = 0; u < U; ++u)
+                    r[u] = load16_stream((const char*)x + (base + (t + u) * hidden + col0) * Elem<DT>::kBytes);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float f[E];
-                unpack<DT>(r[u], f);
+                for (int u = 0; u < U; ++u) {
+                    float f[E];
+                    unpack<DT>(r[u], f);
 #pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const float d = f[i] - x0[i];
-                    sd[i] += d;
-                    sq[i] = fmaf(d, d, sq[i]);
-                    am[i] = fmaxf(am[i], fabsf(f[i]));
+                    for (int i = 0; i < E; ++i) {
+                        const float d = f[i] - x0[i];
+                        sd[i] += d;
+                        sq[i] = fmaf(d, d, sq[i]);
+                        am[i] = fmaxf(am[i], fabsf(f[i]));
+                    }
                 }
             }
         }
-    }
-    for (; t < t1; ++t) {
-        float f[E];
-        if constexpr (VEC) {
-            unpack<DT>(*(const Vec16*)((const char*)x + (base + t * hidden + col0) * Elem<DT>::kBytes), f);
-        } else {
-            f[0] = Elem<DT>::load(x, base + t * hidden + col0);
-        }
+        for (; t < t1; ++t) {
+            float f[E];
+            if constexpr (VEC) {
+                unpack<DT>(*(const Vec16*)((const char*)x + (base + t * hidden + col0) * Elem<DT>::kBytes), f);
+            } else {
+                f[0] = Elem<DT>::load(x, base + t * hidden + col0);
+            }
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const float d = f[i] - x0[i];
-            sd[i] += d;
-            sq[i] = fmaf(d, d, sq[i]);
-            am[i] = fmaxf(am[i], fabsf(f[i]));
+            for (int i = 0; i < E; ++i) {
+                const float d = f[i] - x0[i];
+                sd[i] += d;
+                sq[i] = fmaf(d, d, sq[i]);
+                am[i] = fmaxf(am[i], fabsf(f[i]));
+            }
         }
     }
+    if constexpr (SUB > 1) {
+        if (wv > 0) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                part[wv - 1][0][i][lane] = sd[i];
+                part[wv - 1][1][i][lane] = sq[i];
+                part[wv - 1][2][i][lane] = am[i];
+            }
+        }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll
+        for (int w = 0; w < SUB - 1; ++w) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                sd[i] += part[w][0][i][lane];
+                sq[i] += part[w][1][i][lane];
+                am[i] = fmaxf(am[i], part[w][2][i][lane]);
+            }
+        }
+    }
+    if (!live) return;
     float* p = ws + ((b * nsplit + s) * 3) * hidden + col0;
 #pragma unroll
     for (int i = 0; i < E; ++i) {
@@ -111,49 +146,84 @@ __device__ __forceinline__ float round_like(int dt, float v) {
     return v;
 }
 
-// stage 1 of the merge: thread (k, b) folds the token splits of one (batch, channel) -> column sum for the mean,
-// and the block folds its variance / abs-max / square sums into one partial record (4 doubles).
+// stage 1 of the merge: 256 channels x 4 quarter-ranges of the token splits per block; thread (c, j) folds its
+// quarter of the splits of one (batch, channel) in split order, the quarters are added in order through LDS ->
+// column sum for the mean, and the block folds its variance / abs-max / square sums into one partial record
+// (4 doubles; records == NULL: mean only, the d^2 / abs-max partials are not read).  With mean_direct (one batch
+// item, no statistics) the mean is written here, by finalize's expression, and finalize is not launched.
 // merge workspace layout (after the partials): colsum[batch][hidden] floats, then records[blocks][4] doubles.
 template <int DT>
-__global__ __launch_bounds__(256) void k_act_merge(const void* __restrict__ x, int64_t tokens, int64_t hidden, int nsplit,
-                                                   const float* __restrict__ ws, float* __restrict__ colsum,
-                                                   double* __restrict__ records) {
+__global__ __launch_bounds__(1024) void k_act_merge(const void* __restrict__ x, int64_t tokens, int64_t hidden, int nsplit,
+                                                    const float* __restrict__ ws, float* __restrict__ colsum,
+                                                    double* __restrict__ records, float* __restrict__ mean_direct) {
+    __shared__ float part[3][3][256];
     __shared__ double red[4][4];
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = threadIdx.x & 255, j = threadIdx.x >> 8;
+    const int64_t k = (int64_t)blockIdx.x * 256 + c;
     const int64_t b = blockIdx.y;
     const float T = (float)tokens;
+    const bool want_stats = records != nullptr;
+    const int per = (nsplit + 3) / 4;
+    const int s0 = j * per, s1 = s0 + per < nsplit ? s0 + per : nsplit;
+    float sd = 0.0f, sq = 0.0f, am = 0.0f;
+    if (k < hidden) {
+        if (want_stats) {
+#pragma unroll 4
+            for (int s = s0; s < s1; ++s) {
+                const float* p = ws + ((b * nsplit + s) * 3) * hidden + k;
+                sd += p[0];
+                sq += p[hidden];
+                am = fmaxf(am, p[2 * hidden]);
+            }
+        } else {
+#pragma unroll 8
+            for (int s = s0; s < s1; ++s) sd += ws[((b * nsplit + s) * 3) * hidden + k];
+        }
+    }
+    if (j > 0) {
+        part[j - 1][0][c] = sd;
+        part[j - 1][1][c] = sq;
+        part[j - 1][2][c] = am;
+    }
+    __syncthreads();
     double s_var = 0.0, s_amax = 0.0, s_sq = 0.0;
     float m_var = -__builtin_inff();
-    if (k < hidden) {
-        float sd = 0.0f, sq = 0.0f, am = 0.0f;
-        for (int s = 0; s < nsplit; ++s) {
-            const float* p = ws + ((b * nsplit + s) * 3) * hidden + k;
-            sd += p[0];
-            sq += p[hidden];
-            am = fmaxf(am, p[2 * hidden]);
+    if (j == 0 && k < hidden) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            sd += part[q][0][c];
+            sq += part[q][1][c];
+            am = fmaxf(am, part[q][2][c]);
         }
         const float x0 = Elem<DT>::load(x, b * tokens * hidden + k);
-        float var = (sq - sd * sd / T) / T;
-        var = var < 0.0f ? 0.0f : var;
-        var = round_like(DT, var);  // torch.var returns the input dtype before the outer mean / max
-        s_var = var;
-        m_var = var;
-        s_amax = am;
-        s_sq = (double)sq + 2.0 * (double)x0 * (double)sd + (double)T * (double)x0 * (double)x0;
-        colsum[b * hidden + k] = sd + T * x0;
+        const float total = sd + T * x0;
+        colsum[b * hidden + k] = total;
+        if (mean_direct) mean_direct[k] = (float)((0.0 + (double)total) / ((double)1 * (double)tokens));
+        if (want_stats) {
+            float var = (sq - sd * sd / T) / T;
+            var = var < 0.0f ? 0.0f : var;
+            var = round_like(DT, var);  // torch.var returns the input dtype before the outer mean / max
+            s_var = var;
+            m_var = var;
+            s_amax = am;
+            s_sq = (double)sq + 2.0 * (double)x0 * (double)sd + (double)T * (double)x0 * (double)x0;
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        s_var += __shfl_xor(s_var, off, 64);
-        s_amax += __shfl_xor(s_amax, off, 64);
-        s_sq += __shfl_xor(s_sq, off, 64);
-        m_var = fmaxf(m_var, __shfl_xor(m_var, off, 64));
-    }
+    if (!want_stats) return;  // uniform over the block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        red[0][wave] = s_var;
-        red[1][wave] = s_amax;
-        red[2][wave] = s_sq;
-        red[3][wave] = (double)m_var;
+    if (j == 0) {  // the four waves of quarter 0
+        for (int off = 32; off > 0; off >>= 1) {
+            s_var += __shfl_xor(s_var, off, 64);
+            s_amax += __shfl_xor(s_amax, off, 64);
+            s_sq += __shfl_xor(s_sq, off, 64);
+            m_var = fmaxf(m_var, __shfl_xor(m_var, off, 64));
+        }
+        if (lane == 0) {
+            red[0][wave] = s_var;
+            red[1][wave] = s_amax;
+            red[2][wave] = s_sq;
+            red[3][wave] = (double)m_var;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -223,23 +293,31 @@ static int run_reduce(const void* x, int64_t batch, int64_t tokens, int64_t hidd
                       float* ws, hipStream_t s) {
     const int nsplit = reduce_nsplit(batch, tokens, hidden);
     const bool vec = (((uintptr_t)x & 15u) == 0) && (hidden % Elem<DT>::kPerVec == 0);
+    // four waves per token slice where a slice is long enough to share and the launch would otherwise leave the
+    // chip short of waves; short inputs keep the single-wave form (and its summation order)
+    const int64_t rows_per = (tokens + nsplit - 1) / nsplit;
     if (vec) {
         const int64_t cols_per_block = 64 * Elem<DT>::kPerVec;
         dim3 grid((unsigned)((hidden + cols_per_block - 1) / cols_per_block), (unsigned)nsplit, (unsigned)batch);
-        hipLaunchKernelGGL((k_act_partials<DT, true>), grid, dim3(64), 0, s, x, tokens, hidden, nsplit, ws);
+        const bool share = rows_per >= 32 && tokens >= 256 && (int64_t)grid.x * grid.y * grid.z <= 4096;
+        if (share)
+            hipLaunchKernelGGL((k_act_partials<DT, true, 4>), grid, dim3(256), 0, s, x, tokens, hidden, nsplit, ws);
+        else
+            hipLaunchKernelGGL((k_act_partials<DT, true, 1>), grid, dim3(64), 0, s, x, tokens, hidden, nsplit, ws);
     } else {
         dim3 grid((unsigned)((hidden + 63) / 64), (unsigned)nsplit, (unsigned)batch);
-        hipLaunchKernelGGL((k_act_partials<DT, false>), grid, dim3(64), 0, s, x, tokens, hidden, nsplit, ws);
+        hipLaunchKernelGGL((k_act_partials<DT, false, 1>), grid, dim3(64), 0, s, x, tokens, hidden, nsplit, ws);
     }
     int st = launch_status("act_partials");
     if (st != NNCF_AMD_OK) return st;
     float* colsum = ws + align8(partial_floats(batch, tokens, hidden));
     double* records = (double*)(colsum + align8((size_t)batch * (size_t)hidden));
     const unsigned kb = (unsigned)((hidden + 255) / 256);
-    hipLaunchKernelGGL((k_act_merge<DT>), dim3(kb, (unsigned)batch), dim3(256), 0, s, x, tokens, hidden, nsplit,
-                       (const float*)ws, colsum, records);
+    const bool direct = batch == 1 && mean_out && !stats_out;  // the mean of one sample leaves the merge kernel
+    hipLaunchKernelGGL((k_act_merge<DT>), dim3(kb, (unsigned)batch), dim3(1024), 0, s, x, tokens, hidden, nsplit,
+                       (const float*)ws, colsum, stats_out ? records : (double*)nullptr, direct ? mean_out : (float*)nullptr);
     st = launch_status("act_merge");
-    if (st != NNCF_AMD_OK) return st;
+    if (st != NNCF_AMD_OK || direct) return st;
     hipLaunchKernelGGL(k_act_finalize, dim3(kb), dim3(256), 0, s, batch, tokens, hidden, (const float*)colsum,
                        (const double*)records, (int64_t)kb * batch, mean_out, stats_out);
     return launch_status("act_finalize");

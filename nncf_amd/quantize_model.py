@@ -428,6 +428,7 @@ class WeightCompression:
         hawq: Dict[str, Any] = {n: 0.0 for n in by_name}
         stat_idx = _STAT_INDEX.get(self._sensitivity_metric)
         cache: Dict[Any, Any] = {}
+        mean_dtype: Dict[str, torch.dtype] = {}
         names = {id(wp.module): wp.module_name for wp in targets}
 
         def pre(mod, args, kwargs):
@@ -437,13 +438,14 @@ class WeightCompression:
             hit = cache.get(key)
             if hit is None:
                 mean, stats = activation_stats(x, want_mean=want_mean, want_stats=want_stat)
-                if mean is not None:  # torch.mean accumulates 16-bit floats in fp32 and rounds once to the dtype
-                    mean = mean.to(x.dtype if x.dtype.is_floating_point else torch.float32)
                 hit = cache[key] = (mean, stats, x)  # x kept alive so that its address is not reused within the pass
             mean, stats, _ = hit
             if mean is not None:
-                means[name].mean_values.append(mean.clone())
+                # the fp32 mean as the kernel wrote it, shared by the Linears that read this activation; rounded to
+                # the activation's dtype after the pass (the hook's host time is not hidden behind the forward)
+                means[name].mean_values.append(mean)
                 means[name].shape_values.append(tuple(x.shape))
+                mean_dtype[name] = x.dtype if x.dtype.is_floating_point else torch.float32
             if stats is not None:
                 if self._sensitivity_metric == SensitivityMetric.HESSIAN_INPUT_ACTIVATION:
                     hawq[name] = (hawq[name] + stats[3]) / x.numel()  # collectors.py:929-933
@@ -467,6 +469,16 @@ class WeightCompression:
                 h.remove()
         if n_samples == 0:
             raise ValidationError("Calibration dataset must not be empty.")
+        # torch.mean accumulates 16-bit floats in fp32 and rounds once to the dtype: one stack + cast per distinct
+        # activation; the Linears that read it get the rows of the same buffer (nothing downstream writes into them)
+        rounded: Dict[Any, List[torch.Tensor]] = {}
+        for name, st in means.items():
+            if not st.mean_values:
+                continue
+            key = (tuple(id(m) for m in st.mean_values), mean_dtype[name])
+            if key not in rounded:
+                rounded[key] = list(torch.stack(st.mean_values).to(mean_dtype[name]).unbind(0))
+            st.mean_values = list(rounded[key])
         activation_scores: Dict[str, float] = {}
         if want_stat:
             for name in by_name:
