@@ -61,7 +61,8 @@ def test_reference_literals():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(1, 2048, 4096), (3, 77, 100), (2, 1, 8), (1, 5000, 24), (4, 33, 1030)])
+@pytest.mark.parametrize("shape", [(1, 2048, 4096), (3, 77, 100), (2, 1, 8), (1, 5000, 24), (4, 33, 1030),
+                                   (1, 256, 512), (1, 257, 1032), (2, 1001, 4096), (1, 2048, 14336), (1, 4099, 264)])
 def test_oracle_shapes(shape, dtype):
     """every split/vector path; one channel has a large mean (outlier) to exercise the shifted variance."""
     from nncf_amd import statistics as S
@@ -77,6 +78,9 @@ def test_oracle_shapes(shape, dtype):
     np.testing.assert_allclose(float(stats[1]), O.max_variance_reducer(xr, (1,), dtype), rtol=max(rt, 1e-4))
     np.testing.assert_allclose(float(stats[2]), O.mean_abs_max_reducer(xr, (1,)), rtol=3e-6)
     np.testing.assert_allclose(float(stats[3]), np.sum(xr.astype(np.float64) ** 2), rtol=1e-5)
+    # the mean-only call (one launch less; a single sample's mean leaves the merge kernel) gives the same bits
+    only, none = S.activation_stats(x, want_stats=False)
+    assert none is None and torch.equal(only, mean)
     with pytest.raises(Exception):
         S.MeanReducer(axes=(0,))._reduce_out_of_place([x])
 
