@@ -7,6 +7,7 @@ from __future__ import annotations
 from copy import deepcopy
 from typing import Optional
 
+import numpy as np
 import torch
 
 from nncf_amd import _lib
@@ -20,6 +21,19 @@ FUSED_SEARCH = True  # developer switch: False takes the per-group torch path fo
 GROUPS_PER_LAUNCH = 64
 
 
+def _quantile_rows(x: torch.Tensor, q: float) -> torch.Tensor:
+    """torch.quantile(x, q, dim=1, keepdim=True) ('linear') for a finite 2-D fp32 x, by its own recipe -- sort, the two
+    neighbours of rank q*(n-1) (fp32 arithmetic, as the q tensor of torch.quantile is fp32), torch.lerp -- without the
+    ~10 other kernels of torch.quantile: their code objects cost 0.35 s to load in the first call of a process.
+    (A NaN in a row is not propagated as torch.quantile does; activation magnitudes with NaN are outside the contract.)"""
+    n = x.shape[1]
+    rank = np.float32(q) * np.float32(n - 1)
+    below, above = int(np.floor(rank)), int(np.ceil(rank))
+    weight = float(np.float32(rank - np.float32(below)))
+    srt = torch.sort(x, dim=1)[0]
+    return torch.lerp(srt[:, below:below + 1], srt[:, above:above + 1], weight)
+
+
 def _candidate_scales(gscale, alpha_min, alpha_step, steps, gprev, prev_s, n_prev):
     """cur_scale of every alpha step, [..., steps, gs] for gscale [..., gs] (awq.py:311-335 incl. the fp16-overflow
     clamp; gprev [..., gs] = mean |previous weight| of the group's channels)."""
@@ -28,11 +42,14 @@ def _candidate_scales(gscale, alpha_min, alpha_step, steps, gprev, prev_s, n_pre
     for _ in range(steps):
         alphas.append(alpha)
         alpha += alpha_step
-    alphas_t = torch.tensor(alphas, dtype=torch.float64, device=gscale.device).to(torch.float32)
+    alphas32 = np.asarray(alphas, dtype=np.float64).astype(np.float32)
+    alphas_t = torch.from_numpy(alphas32).to(gscale.device)
     all_scales = torch.pow(gscale.unsqueeze(-2), alphas_t.unsqueeze(-1))
-    half = alphas_t == 0.5  # tensor ** python-scalar takes the sqrt path for exactly 0.5
-    if bool(half.any()):
-        all_scales[..., half, :] = torch.sqrt(gscale).unsqueeze(-2)
+    half = np.nonzero(alphas32 == np.float32(0.5))[0]  # tensor ** python-scalar takes the sqrt path for exactly 0.5
+    if half.size:
+        root = torch.sqrt(gscale)
+        for j in half.tolist():
+            all_scales[..., j, :] = root
     if prev_s is not None:
         threshold = FP16_OVERFLOW_MARGIN * FP16_MAX_VALUE
         # awq.py:321-335, same operation order: (prev_w / cur_scale) * prev_s * n  vs  prev_w * prev_s * n / threshold
@@ -65,7 +82,7 @@ def _fused_group_search(weight, s, X, config, group_size, groups, scale, alpha_m
         gscale = s.reshape(B, G, group_size)[bi, gi]                       # [nc, gs]
         gweight = w4[bi, :, gi, :]                                      # [nc, N, gs]
         gacts = X.reshape(B, G, group_size, n)[bi, gi]                  # [nc, gs, n]
-        a_min = torch.quantile(gscale, 0.1, dim=1, keepdim=True).to(torch.float32)
+        a_min = _quantile_rows(gscale, 0.1)
         gscale = torch.minimum(torch.maximum(gscale, a_min), torch.full_like(gscale, 1e2))
         fp_out = torch.matmul(gweight, gacts).contiguous()              # [nc, N, n]
         min_diff = fp_out.abs().amax(dim=(1, 2))
@@ -120,7 +137,7 @@ def data_aware_step(weight: torch.Tensor, reduction_axes, config: WeightCompress
         prev_s = prev_s.to(torch.float32).max().item()
         prev_w = torch.mean(torch.abs(prev_weight.to(torch.float32)), dim=reduction_axis)
     top_k = max(int(s.shape[-1] * percent_to_apply), 1)
-    topk_idxs = torch.argsort(-s, stable=True)[:, :top_k].cpu()
+    topk_idxs = torch.sort(-s, dim=-1, stable=True)[1][:, :top_k].cpu()
     group_size = config.group_size if config.group_size != -1 else s.shape[-1]
     groups_to_correct = set()
     for batch_idx in range(topk_idxs.shape[0]):

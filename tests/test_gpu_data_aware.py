@@ -598,3 +598,22 @@ def test_gptq_node_3d_weight_vs_oracle(mode, gs):
         if z_ref is not None:
             assert (host(z[e]) == z_ref).mean() >= 0.99
     assert (z is None) == (mode != "int4_asym")
+
+
+@pytest.mark.gpu
+def test_awq_preparation_helpers_equal_the_torch_ops():
+    """awq._quantile_rows replaces torch.quantile in the search preparation (its code objects are the first AWQ call's
+    largest one-time cost): same bits on finite inputs, ties and constant rows included."""
+    from nncf_amd import awq
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n in (8, 16, 32, 64, 100, 128, 256):
+        x = torch.rand((40, n), device="cuda", generator=g) * 3 + 1e-3
+        x[1] = 0.25                      # constant row
+        x[2, : n // 2] = x[2, 0]         # ties around the rank
+        x[3] = x[3].round()              # few distinct values
+        for q in (0.1, 0.5, 0.9):
+            want = torch.quantile(x, q, dim=1, keepdim=True)
+            got = awq._quantile_rows(x, q)
+            assert got.shape == want.shape and torch.equal(got, want), (n, q)
+    s = torch.rand((2, 500), device="cuda", generator=g).round(decimals=2)  # many equal keys: stable order matters
+    assert torch.equal(torch.sort(-s, dim=-1, stable=True)[1], torch.argsort(-s, stable=True))
