@@ -2,7 +2,8 @@
 // Reference: get_integer_quantization_error (src/nncf/quantization/algorithms/weight_compression/weight_lowering.py
 // :329-374) inside the mixed-precision scoring loop (mixed_precision.py:161-199): quantize -> dequantize -> squared
 // difference -> mean over the row -> max over the rows (or the Frobenius norm).
-// One block per row (ws[row] keeps the layout of the row-per-block kernel in wc_misc.hip); its four waves take the
+// One block per row (ws[row] keeps the layout of the row-per-block kernel in wc_misc.hip); its WPB waves (as many as
+// the shortest row of the launch has tiles, at most four: a [N, 4096] bf16 row is two tiles) take the
 // row's 4-KiB tiles in turn with the tile kernel's structure (wc_group_kernels.h: LDS-DMA, a lane owns 64
 // contiguous bytes, DPP min/max over the group's lanes, quant_n_div) and add d^2 = (dequantized - w)^2 per lane; lanes
 // -> wave -> block sums run in a fixed order, so the result does not depend on scheduling.  The kernel it replaces
@@ -12,8 +13,8 @@
 
 namespace wc {
 
-template <typename Policy, int DT, int VPG>
-__global__ __launch_bounds__(256) void k_err_tiles(ErrBatchArgs a, float* __restrict__ ws) {
+template <typename Policy, int DT, int VPG, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_err_tiles(ErrBatchArgs a, float* __restrict__ ws) {
     constexpr int VPL = kVPL;
     constexpr int E = Elem<DT>::kPerVec;
     constexpr int NE = VPL * E;
@@ -21,8 +22,8 @@ __global__ __launch_bounds__(256) void k_err_tiles(ErrBatchArgs a, float* __rest
     constexpr int LPG = VPG >= VPL ? VPG / VPL : 1;
     constexpr int SG = NE / GPL;
     constexpr int TILE = 64 * VPL;
-    __shared__ Vec16 stage[4][TILE];
-    __shared__ float wsum[4];
+    __shared__ Vec16 stage[WPB][TILE];
+    __shared__ float wsum[WPB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t grow = blockIdx.x;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void k_err_tiles(ErrBatchArgs a, float* __rest
     o.mode = a.mode;
     const Policy pol(o, nullptr);
     float acc = 0.0f;
-    for (uint32_t v0 = (uint32_t)wave * TILE; v0 < vpr; v0 += 4 * TILE) {
+    for (uint32_t v0 = (uint32_t)wave * TILE; v0 < vpr; v0 += WPB * TILE) {
         const uint32_t in_tile = vpr - v0 < (uint32_t)TILE ? vpr - v0 : (uint32_t)TILE;
         const uint32_t last = (in_tile - 1) * 16u;
 #pragma unroll
@@ -80,30 +81,44 @@ __global__ __launch_bounds__(256) void k_err_tiles(ErrBatchArgs a, float* __rest
         if ((uint32_t)(lane * VPL) < in_tile) acc += part;  // (a lane is all live or all dead)
     }
     acc = lanes_allreduce<64>(acc, OpAdd());
-    if (lane == 0) wsum[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) ws[grow] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if constexpr (WPB == 1) {
+        if (lane == 0) ws[grow] = acc;
+    } else {
+        if (lane == 0) wsum[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if constexpr (WPB == 2) ws[grow] = wsum[0] + wsum[1];
+            else ws[grow] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        }
+    }
 }
 
-template <typename Policy, int DT>
+template <typename Policy, int DT, int WPB>
 static bool err_tiles_vpg(int vpg, const ErrBatchArgs& a, float* ws, hipStream_t s) {
     const dim3 grid(a.row_start[a.n]);
     switch (vpg) {
-        case 4: hipLaunchKernelGGL((k_err_tiles<Policy, DT, 4>), grid, dim3(256), 0, s, a, ws); return true;
-        case 8: hipLaunchKernelGGL((k_err_tiles<Policy, DT, 8>), grid, dim3(256), 0, s, a, ws); return true;
-        case 16: hipLaunchKernelGGL((k_err_tiles<Policy, DT, 16>), grid, dim3(256), 0, s, a, ws); return true;
-        case 32: hipLaunchKernelGGL((k_err_tiles<Policy, DT, 32>), grid, dim3(256), 0, s, a, ws); return true;
+        case 4: hipLaunchKernelGGL((k_err_tiles<Policy, DT, 4, WPB>), grid, dim3(64 * WPB), 0, s, a, ws); return true;
+        case 8: hipLaunchKernelGGL((k_err_tiles<Policy, DT, 8, WPB>), grid, dim3(64 * WPB), 0, s, a, ws); return true;
+        case 16: hipLaunchKernelGGL((k_err_tiles<Policy, DT, 16, WPB>), grid, dim3(64 * WPB), 0, s, a, ws); return true;
+        case 32: hipLaunchKernelGGL((k_err_tiles<Policy, DT, 32, WPB>), grid, dim3(64 * WPB), 0, s, a, ws); return true;
         default: return false;
     }
 }
 
+template <typename Policy, int DT>
+static bool err_tiles_wpb(int vpg, int wpb, const ErrBatchArgs& a, float* ws, hipStream_t s) {
+    if (wpb >= 4) return err_tiles_vpg<Policy, DT, 4>(vpg, a, ws, s);
+    if (wpb >= 2) return err_tiles_vpg<Policy, DT, 2>(vpg, a, ws, s);
+    return err_tiles_vpg<Policy, DT, 1>(vpg, a, ws, s);
+}
+
 template <int DT>
-static bool err_tiles_mode(int vpg, const ErrBatchArgs& a, float* ws, hipStream_t s) {
+static bool err_tiles_mode(int vpg, int wpb, const ErrBatchArgs& a, float* ws, hipStream_t s) {
     switch (a.mode) {
-        case NNCF_AMD_INT8_ASYM: return err_tiles_vpg<IntPolicyT<NNCF_AMD_INT8_ASYM>, DT>(vpg, a, ws, s);
-        case NNCF_AMD_INT8_SYM: return err_tiles_vpg<IntPolicyT<NNCF_AMD_INT8_SYM>, DT>(vpg, a, ws, s);
-        case NNCF_AMD_INT4_ASYM: return err_tiles_vpg<IntPolicyT<NNCF_AMD_INT4_ASYM>, DT>(vpg, a, ws, s);
-        case NNCF_AMD_INT4_SYM: return err_tiles_vpg<IntPolicyT<NNCF_AMD_INT4_SYM>, DT>(vpg, a, ws, s);
+        case NNCF_AMD_INT8_ASYM: return err_tiles_wpb<IntPolicyT<NNCF_AMD_INT8_ASYM>, DT>(vpg, wpb, a, ws, s);
+        case NNCF_AMD_INT8_SYM: return err_tiles_wpb<IntPolicyT<NNCF_AMD_INT8_SYM>, DT>(vpg, wpb, a, ws, s);
+        case NNCF_AMD_INT4_ASYM: return err_tiles_wpb<IntPolicyT<NNCF_AMD_INT4_ASYM>, DT>(vpg, wpb, a, ws, s);
+        case NNCF_AMD_INT4_SYM: return err_tiles_wpb<IntPolicyT<NNCF_AMD_INT4_SYM>, DT>(vpg, wpb, a, ws, s);
         default: return false;
     }
 }
@@ -113,14 +128,18 @@ bool err_tiles_launch(int w_dtype, const ErrBatchArgs& a, float* ws, hipStream_t
     if (a.gs < 1 || a.n < 1 || a.row_start[a.n] == 0 || (a.gs * eb) % 16 != 0) return false;
     const int64_t vpg = a.gs * eb / 16;
     if (vpg != 4 && vpg != 8 && vpg != 16 && vpg != 32) return false;
+    int64_t min_tiles = 4;  // waves per block: the tiles of the shortest row, so that no wave of a block is idle
     for (int i = 0; i < a.n; ++i) {
         // rows of whole lanes (64 bytes), 16-byte aligned tensors
         if (((int64_t)a.cols[i] * eb) % (16 * kVPL) != 0 || !is16(a.w[i])) return false;
+        const int64_t tiles = ((int64_t)a.cols[i] * eb + 4095) / 4096;
+        if (tiles < min_tiles) min_tiles = tiles;
     }
+    const int wpb = (int)min_tiles;
     switch (w_dtype) {
-        case NNCF_AMD_F32: return err_tiles_mode<NNCF_AMD_F32>((int)vpg, a, ws, s);
-        case NNCF_AMD_F16: return err_tiles_mode<NNCF_AMD_F16>((int)vpg, a, ws, s);
-        case NNCF_AMD_BF16: return err_tiles_mode<NNCF_AMD_BF16>((int)vpg, a, ws, s);
+        case NNCF_AMD_F32: return err_tiles_mode<NNCF_AMD_F32>((int)vpg, wpb, a, ws, s);
+        case NNCF_AMD_F16: return err_tiles_mode<NNCF_AMD_F16>((int)vpg, wpb, a, ws, s);
+        case NNCF_AMD_BF16: return err_tiles_mode<NNCF_AMD_BF16>((int)vpg, wpb, a, ws, s);
         default: return false;
     }
 }
