@@ -50,6 +50,7 @@ struct ErrBatchArgs {
 // Launches the tile kernel over the rows of `a` when its shape conditions hold (returns false otherwise, nothing
 // launched): ws[global row] = sum of squared quantization errors of the row.
 bool err_tiles_launch(int w_dtype, const ErrBatchArgs& a, float* ws, hipStream_t s);
+bool err_rows_launch(int w_dtype, const ErrBatchArgs& a, float* ws, hipStream_t s);  // whole-row groups (wc_int_rows.hip)
 
 // ---------------------------------------------------------------- 16-byte vectors of the input dtype
 struct alignas(16) Vec16 {

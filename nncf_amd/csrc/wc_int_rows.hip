@@ -24,4 +24,18 @@ int int_rows_run(int w_dtype, const BatchItem* items, int n, int mode, const cha
     }
 }
 
+// Per-channel error metric of the tensors of one launch (nncf_amd_int_quant_error[_batched] with group_size -1 or
+// the row length): the row kernel without its stores.  The mode is read at run time here (one set of kernels).
+bool err_rows_launch(int w_dtype, const ErrBatchArgs& a, float* ws, hipStream_t s) {
+    if (a.n < 1 || a.row_start[a.n] == 0) return false;
+    for (int i = 0; i < a.n; ++i)
+        if (a.gs != -1 && a.gs != (int64_t)a.cols[i]) return false;
+    switch (w_dtype) {
+        case NNCF_AMD_F32: return run_err_rows<IntPolicy, NNCF_AMD_F32>(a, ws, s);
+        case NNCF_AMD_F16: return run_err_rows<IntPolicy, NNCF_AMD_F16>(a, ws, s);
+        case NNCF_AMD_BF16: return run_err_rows<IntPolicy, NNCF_AMD_BF16>(a, ws, s);
+        default: return false;
+    }
+}
+
 }  // namespace wc

@@ -378,7 +378,7 @@ extern "C" int nncf_amd_int_quant_error(const void* weight, int w_dtype, int64_t
         set_error("int_quant_error: unsupported weight dtype %d", w_dtype);
         return NNCF_AMD_ERR_DTYPE;
     }
-    if (inner == 1 && r <= 0x7fffffff) {  // a [rows, cols] weight: the tile kernel when its shape conditions hold
+    if (inner == 1 && r <= 0x7fffffff) {  // a [rows, cols] weight: the tile / row kernel when its shape conditions hold
         ErrBatchArgs a = {};
         a.n = 1;
         a.mode = mode;
@@ -388,7 +388,7 @@ extern "C" int nncf_amd_int_quant_error(const void* weight, int w_dtype, int64_t
         a.row_start[1] = (uint32_t)channels;
         a.cols[0] = (uint32_t)r;
         a.w[0] = weight;
-        if (err_tiles_launch(w_dtype, a, ws, s)) {
+        if (err_tiles_launch(w_dtype, a, ws, s) || err_rows_launch(w_dtype, a, ws, s)) {
             int st = launch_status("err_tiles");
             if (st != NNCF_AMD_OK) return st;
             hipLaunchKernelGGL(k_err_final, dim3(1), dim3(256), 0, s, (const float*)ws, channels, r, reduction, result);
@@ -481,6 +481,7 @@ extern "C" int nncf_amd_int_quant_error_batched(int n, const void* const* weight
         a.n = j;
         const dim3 grid((unsigned)acc);
         if (err_tiles_launch(w_dtype, a, ws, s)) {  // grouped modes on 16-byte rows: the tile kernel (wc_int_err.hip)
+        } else if (err_rows_launch(w_dtype, a, ws, s)) {  // whole-row groups: the row kernel without its stores
         } else
         switch (w_dtype) {
             case NNCF_AMD_F32: hipLaunchKernelGGL((k_err_rows_batch<NNCF_AMD_F32>), grid, dim3(256), 0, s, a, ws); break;

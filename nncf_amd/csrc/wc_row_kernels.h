@@ -7,6 +7,8 @@
 // has a whole row in flight).  Wave-owned rows come out of LDS so that a lane owns PAIRS of adjacent vectors and
 // its codes leave as 16-byte streaming stores.
 #pragma once
+#include <type_traits>
+
 #include "wc_group_kernels.h"
 
 namespace wc {
@@ -27,12 +29,16 @@ __device__ __forceinline__ Vec16 load16_nt(const Vec16* p) {
 // order, occupancy hides the load latency (same finding as for the tile kernel, wc_group_kernels.h: 0.775 of the
 // HBM roofline for Llama-3-8B INT8_ASYM; a resident set of teams claiming rows from atomic counters and
 // prefetching the next row stopped at 0.68).
-template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED>
+// ERR: nothing is stored but the row's sum of squared quantization errors, (float*)scale[i])[row] (the error metric
+// of the mixed-precision scoring, weight_lowering.py:329-374 with the per-channel backup configuration): lanes ->
+// waves -> block in a fixed order.
+template <typename Policy, int DT, int TEAM, int KEEP, bool PACKED, bool ERR = false>
 __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
     constexpr int E = Elem<DT>::kPerVec;
     constexpr int TPB = 256 / TEAM;
     __shared__ float lds[kPolicyLds];
     __shared__ typename Policy::Stat wave_stat[4];
+    __shared__ float wave_err[4];
     constexpr bool DMA = TEAM == 64 || KEEP <= 8;
     __shared__ Vec16 stage[TEAM == 64 ? 4 : 1][DMA ? TEAM * KEEP : 1];
     const int lane = threadIdx.x & 63;
@@ -106,11 +112,32 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
         for (int q = 1; q < 4; ++q) pol.stat_merge(st, wave_stat[q]);
     }
     const typename Policy::Par par = pol.compute(st);
-    o.scale_out = b.scale[lo_i];
-    o.zp_out = (int32_t*)b.aux[lo_i];
-    if (tl == 0) pol.template store<true>(o, (int64_t)row, par);
-    if constexpr (PACKED) o.packed = b.packed[lo_i];
-    else o.codes = b.packed[lo_i];
+    if constexpr (!ERR) {
+        o.scale_out = b.scale[lo_i];
+        o.zp_out = (int32_t*)b.aux[lo_i];
+        if (tl == 0) pol.template store<true>(o, (int64_t)row, par);
+        if constexpr (PACKED) o.packed = b.packed[lo_i];
+        else o.codes = b.packed[lo_i];
+    }
+    float err = 0.0f;
+    // N elements: quantize in place, then codes out (or, ERR, the squared differences of the dequantized values)
+    auto emit = [&](auto n_tag, float* f, int64_t e0) {
+        constexpr int N = decltype(n_tag)::value;
+        if constexpr (ERR) {
+            float w0[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) w0[i] = f[i];
+            pol.template quant_n_div<N>(par, f, f);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float d = pol.dq(0, f[i], par) - w0[i];
+                err = fmaf(d, d, err);
+            }
+        } else {
+            pol.template quant_n_div<N>(par, f, f);
+            pol.template store_codes<N, true>(o, f, e0);
+        }
+    };
     auto opaque = [](Vec16 raw) {
         asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));
         return raw;
@@ -124,13 +151,11 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
                 float f[2 * E];
                 unpack<DT>(opaque(cur[k]), f);
                 unpack<DT>(opaque(cur[k + 1]), f + E);
-                pol.template quant_n_div<2 * E>(par, f, f);
-                pol.template store_codes<2 * E, true>(o, f, (int64_t)((row * vpr + j) * E));
+                emit(std::integral_constant<int, 2 * E>(), f, (int64_t)((row * vpr + j) * E));
             } else if (j < vpr) {
                 float f[E];
                 unpack<DT>(opaque(cur[k]), f);
-                pol.template quant_n_div<E>(par, f, f);
-                pol.template store_codes<E, true>(o, f, (int64_t)((row * vpr + j) * E));
+                emit(std::integral_constant<int, E>(), f, (int64_t)((row * vpr + j) * E));
             }
         }
     } else {
@@ -141,9 +166,19 @@ __global__ __launch_bounds__(256) void k_rows_batch(BatchArgs b) {
             if (j < vpr) {
                 float f[E];
                 unpack<DT>(opaque(cur[k]), f);
-                pol.template quant_n_div<E>(par, f, f);
-                pol.template store_codes<E, true>(o, f, (int64_t)((row * vpr + j) * E));
+                emit(std::integral_constant<int, E>(), f, (int64_t)((row * vpr + j) * E));
             }
+        }
+    }
+    if constexpr (ERR) {
+        float* dst = (float*)b.scale[lo_i];
+        err = lanes_allreduce<64>(err, OpAdd());
+        if constexpr (TEAM == 64) {
+            if (lane == 0) dst[row] = err;
+        } else {
+            if (lane == 0) wave_err[wave] = err;
+            __syncthreads();  // (block teams: `have` is uniform over the block)
+            if (threadIdx.x == 0) dst[row] = (wave_err[0] + wave_err[1]) + (wave_err[2] + wave_err[3]);
         }
     }
 }
@@ -187,6 +222,54 @@ static hipError_t dispatch_rows(RowClass c, BatchArgs& b, hipStream_t s) {
         case 8: return launch_rows<Policy, DT, 256, 8, PACKED>(b, s);
         default: return launch_rows<Policy, DT, 256, 16, PACKED>(b, s);
     }
+}
+
+// The error metric of whole-row groups for the tensors of one ErrBatchArgs launch (class by class, like run_rows).
+// false: some tensor does not fit (the caller falls back to the generic kernel for the whole launch).
+template <typename Policy, int DT>
+static bool run_err_rows(const ErrBatchArgs& a, float* ws, hipStream_t s) {
+    constexpr int eb = DT == NNCF_AMD_F32 ? 4 : 2;
+    static_assert(kErrBatch <= kMaxBatch, "one BatchArgs takes a whole ErrBatchArgs launch");
+    for (int i = 0; i < a.n; ++i)
+        if (((int64_t)a.cols[i] * eb) % 16 != 0 || !is16(a.w[i]) || row_class((int64_t)a.cols[i] * eb / 16).team == 0) return false;
+    char done[kErrBatch] = {};
+    for (int first = 0; first < a.n; ++first) {
+        if (done[first]) continue;
+        const RowClass c = row_class((int64_t)a.cols[first] * eb / 16);
+        BatchArgs b = {};
+        b.mode = a.mode;
+        int j = 0;
+        uint32_t acc = 0;
+        for (int k = first; k < a.n; ++k) {
+            const RowClass ck = row_class((int64_t)a.cols[k] * eb / 16);
+            if (done[k] || ck.team != c.team || ck.keep != c.keep) continue;
+            b.tile_start[j] = acc;
+            b.nfull[j] = (uint32_t)((int64_t)a.cols[k] * eb / 16);
+            b.w[j] = a.w[k];
+            b.scale[j] = ws + a.row_start[k];
+            acc += a.row_start[k + 1] - a.row_start[k];
+            b.tile_start[++j] = acc;
+            done[k] = 1;
+        }
+        b.n = j;
+        const unsigned blocks = c.team == 64 ? (acc + 3) / 4 : acc;
+        const dim3 grid(blocks), blk(256);
+        if (c.team == 64) {
+            switch (c.keep) {
+                case 1: hipLaunchKernelGGL((k_rows_batch<Policy, DT, 64, 1, false, true>), grid, blk, 0, s, b); break;
+                case 2: hipLaunchKernelGGL((k_rows_batch<Policy, DT, 64, 2, false, true>), grid, blk, 0, s, b); break;
+                case 4: hipLaunchKernelGGL((k_rows_batch<Policy, DT, 64, 4, false, true>), grid, blk, 0, s, b); break;
+                default: hipLaunchKernelGGL((k_rows_batch<Policy, DT, 64, 8, false, true>), grid, blk, 0, s, b); break;
+            }
+        } else {
+            switch (c.keep) {
+                case 4: hipLaunchKernelGGL((k_rows_batch<Policy, DT, 256, 4, false, true>), grid, blk, 0, s, b); break;
+                case 8: hipLaunchKernelGGL((k_rows_batch<Policy, DT, 256, 8, false, true>), grid, blk, 0, s, b); break;
+                default: hipLaunchKernelGGL((k_rows_batch<Policy, DT, 256, 16, false, true>), grid, blk, 0, s, b); break;
+            }
+        }
+    }
+    return true;
 }
 
 // Can every item run as whole-row groups?  (16-byte rows, aligned pointers, rows of at most 4096 vectors)

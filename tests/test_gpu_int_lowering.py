@@ -412,6 +412,28 @@ def test_batched_error_metric_vs_oracle_and_single(mode, gs, reduction, dtype):
         wl.get_integer_quantization_errors([torch.zeros(4, 30, device="cuda")], [(1,)], _cfg("int4_sym", 16), "max_mean")
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("mode", ["int8_asym", "int8_sym", "int4_asym"])
+def test_per_channel_error_metric_long_and_odd_rows(mode, dtype):
+    """Whole-row groups (the backup configuration the mixed-precision scoring measures): every team / keep class of
+    the row kernel up to its longest row, a ragged last vector pair, and a launch that falls back to the generic
+    kernel (a row that is not a multiple of 16 bytes) -- batched and per weight, against the oracle."""
+    from nncf_amd import weight_lowering as wl
+    rng = np.random.default_rng(11)
+    for shapes in ([(5, 14336), (2, 8192), (3, 16384), (9, 2056), (4, 136)], [(6, 1000), (3, 30), (2, 4096)]):
+        ws32 = [representable((rng.standard_normal(s) * 0.02 + (0.01 if i % 2 else 0.0)).astype(np.float32), dtype)
+                for i, s in enumerate(shapes)]
+        ws = [to_dev(w, dtype) for w in ws32]
+        cfg = _cfg(mode, -1)
+        for reduction in ("max_mean", "frobenius"):
+            got = wl.get_integer_quantization_errors(ws, [(1,)] * len(ws), cfg, reduction)
+            for i, w32 in enumerate(ws32):
+                ref = O.get_integer_quantization_error(w32, (1,), mode, -1, reduction)
+                np.testing.assert_allclose(got[i], ref, rtol=1e-4, atol=1e-12)
+                one = wl.get_integer_quantization_error(ws[i], (1,), cfg, reduction)
+                np.testing.assert_allclose(got[i], one, rtol=2e-6, atol=1e-12)
+
+
 @pytest.mark.parametrize("mode,gs", [("int4_sym", 64), ("int4_asym", 32), ("int8_asym", -1), ("nf4", 32), ("mxfp4", 32)])
 def test_batched_lowering_of_3d_moe_weights(mode, gs):
     """compress_weights_packed_batched with 3-D / MoE weights [experts, out, in] mixed with 2-D ones: codes, scales and
