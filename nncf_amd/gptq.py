@@ -23,6 +23,18 @@ from nncf_amd.statistics import WCTensorStatistic, activations_to_wc_statistics
 
 HESSIAN_CHUNK_TOKENS = 32768  # tokens per SYRK launch: the MFMA kernel reaches its rate from ~16k tokens on
 HESSIAN_CHUNK_BYTES = 1 << 30
+HESSIAN_LIST_MAX_TOKENS = 262144  # the item-list kernel copies nothing: the buffered items are only kept referenced
+
+
+def _list_chunk_tokens(k: int) -> int:
+    """Tokens per launch of the item-list SYRK kernel.  With few 256 x 256 tiles of H (small K) the kernel splits the
+    token axis over ~2048 blocks (csrc/wc_hessian.hip: launch_syrk16b_list) and every block ends with 65536 atomic
+    adds, so a block should see ~16k tokens: 128 x [2048, 4096] bf16 items took 5.5 ms in 32k-token launches and
+    3.8 ms in one launch (800 -> 1150 TFLOP/s); from K = 8192 on the default already gives a block that many."""
+    nt = (k + 255) // 256
+    pairs = nt * (nt + 1) // 2
+    splits = max(1, -(-2048 // pairs))
+    return min(HESSIAN_LIST_MAX_TOKENS, max(HESSIAN_CHUNK_TOKENS, 16384 * splits))
 
 
 class HessianAccumulator:
@@ -31,8 +43,10 @@ class HessianAccumulator:
     scaled once.  Items are buffered and concatenated into chunks of ~32k tokens per SYRK launch: one long launch
     runs the MFMA kernel at 3x the rate of sixteen 2048-token ones."""
 
-    def __init__(self, k: int, device, chunk_tokens: int = HESSIAN_CHUNK_TOKENS):
-        self.k, self.nsamples, self._chunk_tokens = k, 0, chunk_tokens
+    def __init__(self, k: int, device, chunk_tokens: Optional[int] = None):
+        self.k, self.nsamples = k, 0
+        self._chunk_tokens = chunk_tokens or HESSIAN_CHUNK_TOKENS
+        self._list_tokens = chunk_tokens or _list_chunk_tokens(k)
         self.H = torch.zeros((k, k), dtype=torch.float32, device=device)
         self._buf: List[torch.Tensor] = []
         self._buf_tokens = self._buf_bs = 0
@@ -47,7 +61,10 @@ class HessianAccumulator:
         self._buf.append(x2d)
         self._buf_tokens += x2d.shape[0]
         self._buf_bs += batch_size
-        if (self._buf_tokens >= self._chunk_tokens
+        if x2d.dtype != torch.float32 and self.k >= 2048:  # the item-list kernel (flush): no concatenation copy
+            if self._buf_tokens >= self._list_tokens:
+                self.flush()
+        elif (self._buf_tokens >= self._chunk_tokens
                 or self._buf_tokens * self.k * x2d.element_size() >= HESSIAN_CHUNK_BYTES):
             self.flush()
 
