@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Randomized parity campaign: the HIP lowering (single-tensor and multi-tensor entry points, every mode) against the
+oracle on random shapes, group sizes, dtypes and value distributions; bit-exact codes / scales / zero points.
+
+Not collected by pytest (no test_ prefix); run on a GPU box as
+
+    python -m tests.fuzz_parity --cases 3000 --seed 0
+
+It prints a summary line and every mismatch (seed + case description reproduce it).  The fixed-seed parity tests of
+tests/test_gpu_*.py stay the gate; this widens the net (results of the last run: DESIGN.md section 3)."""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+from oracle import wc_oracle as O
+from tests.gpu_utils import host, representable, to_dev
+
+INT_MODES = ["int8_asym", "int8_sym", "int4_asym", "int4_sym"]
+FLOAT_MODES = ["nf4", "mxfp4"]
+
+
+def _cfg(mode, gs):
+    from nncf_amd.parameters import WeightCompressionConfig
+    return WeightCompressionConfig(mode, gs)
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.dtype.kind == "f":
+        return bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+    return bool((a == b).all())
+
+
+def random_values(rng, shape):
+    """One of several distributions: plain normal at a random magnitude, outlier channels, constant / zero groups,
+    values on and next to rounding ties, a wide dynamic range."""
+    kind = rng.integers(0, 7)
+    mag = np.float32(10.0 ** rng.uniform(-6, 3))
+    w = rng.standard_normal(shape).astype(np.float32) * mag
+    if kind == 1:  # outlier columns
+        idx = rng.integers(0, shape[-1], max(1, shape[-1] // 50))
+        w[..., idx] *= np.float32(rng.uniform(5, 50))
+    elif kind == 2:  # some constant or zero runs
+        flat = w.reshape(-1)
+        for _ in range(3):
+            a = int(rng.integers(0, flat.size))
+            b = min(flat.size, a + int(rng.integers(1, 300)))
+            flat[a:b] = 0.0 if rng.random() < 0.5 else flat[a]
+    elif kind == 3:  # integers + 0.5 times a step: exact ties for the symmetric modes' scales
+        step = np.float32(2.0 ** rng.integers(-12, 4))
+        w = (rng.integers(-8, 8, shape).astype(np.float32) + np.float32(0.5)) * step
+        flat = w.reshape(-1)
+        sel = rng.random(flat.size) < 0.3
+        flat[sel] = np.nextafter(flat[sel], np.float32(np.inf if rng.random() < 0.5 else -np.inf))
+    elif kind == 4:  # wide dynamic range inside a row
+        w = w * np.float32(10.0) ** rng.uniform(-3, 3, shape).astype(np.float32)
+    elif kind == 5:  # all positive / all negative rows (asymmetric zero points at the range ends)
+        w = np.abs(w) * (np.float32(1.0) if rng.random() < 0.5 else np.float32(-1.0))
+    return w.astype(np.float32)
+
+
+def random_case(rng):
+    mode = str(rng.choice(INT_MODES + FLOAT_MODES))
+    dtype = str(rng.choice(["f32", "bf16", "f16"]))
+    if mode == "mxfp4":
+        gs = 32
+    elif mode.startswith("int8") and rng.random() < 0.6:
+        gs = -1
+    else:
+        gs = int(rng.choice([-1, 4, 8, 16, 32, 64, 128, 256, 24, 96]))
+    rows = int(rng.integers(1, 200))
+    if gs == -1:
+        cols = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(1, 40)) * 8, int(rng.choice([512, 1024, 4096, 5120]))]))
+    else:
+        cols = gs * int(rng.integers(1, max(2, 2048 // gs)))
+    three_d = rng.random() < 0.1
+    shape = (int(rng.integers(1, 4)), rows, cols) if three_d else (rows, cols)
+    return mode, dtype, gs, shape
+
+
+def check_case(rng, wl, stats, failures, batched_pool):
+    mode, dtype, gs, shape = random_case(rng)
+    desc = f"{mode} g{gs} {dtype} {shape}"
+    w32 = representable(random_values(rng, shape), dtype)
+    if dtype == "f16":
+        w32 = np.clip(w32, -60000.0, 60000.0)
+    w = to_dev(w32, dtype)
+    axis = len(shape) - 1
+    rc, rs, rz = O.compress_weight(w32, (axis,), mode, gs)
+    cw = wl.compress_weight(w, (axis,), _cfg(mode, gs))
+    ok = _same(host(cw.tensor), rc) and _same(host(cw.scale), rs) and (rz is None or _same(host(cw.zero_point), rz))
+    stats["single"] += 1
+    if not ok:
+        failures.append("single " + desc)
+    # the same weight against GIVEN parameters (another tensor's scale, perturbed): the path scale estimation, AWQ
+    # and GPTQ results take into the lowering; and the quantize-dequantize form
+    from nncf_amd.parameters import CompressedWeight
+    if mode in INT_MODES and rng.random() < 0.5:
+        factor = np.float32(rng.uniform(0.3, 3.0))
+        gscale = (rs * factor).astype(np.float32)
+        gzp = None if rz is None else np.clip(rz + rng.integers(-2, 3, rz.shape), 0, 255 if "8" in mode else 15).astype(rz.dtype)
+        rc2, rs2, rz2 = O.compress_weight(w32, (axis,), mode, gs, gscale, gzp)
+        pre = CompressedWeight(None, torch.from_numpy(gscale).cuda(), None if gzp is None else torch.from_numpy(gzp).cuda())
+        cw2 = wl.compress_weight(w, (axis,), _cfg(mode, gs), pre)
+        stats["given"] += 1
+        if not _same(host(cw2.tensor), rc2):
+            failures.append("given-parameters " + desc)
+        if shape[-1] % 2 == 0 and mode.startswith("int4"):
+            packed = wl.compress_weight_packed(w, (axis,), _cfg(mode, gs), pre)
+            ref = O.pack_uint4(rc2) if mode == "int4_asym" else O.pack_int4(rc2)
+            if not _same(host(packed.tensor).reshape(-1), np.asarray(ref).reshape(-1)):
+                failures.append("given-parameters packed " + desc)
+    if rng.random() < 0.3:
+        if mode in INT_MODES:
+            dq = wl.integer_quantize_dequantize_weight(w, _cfg(mode, gs), (axis,))
+            rdq = O.integer_quantize_dequantize_weight(w32, mode, gs, (axis,))
+        else:
+            dq = wl.float_quantize_dequantize_weight(w, _cfg(mode, gs), (axis,))
+            rdq = O.float_quantize_dequantize_weight(w32, mode, gs, (axis,))
+        stats["qdq"] += 1
+        if not _same(host(dq), rdq):
+            failures.append("quantize-dequantize " + desc)
+    if len(shape) == 2 and (shape[1] % 2 == 0 or mode.startswith("int8")):
+        batched_pool.setdefault((mode, gs, dtype), []).append((w, w32, rc, rs, rz, desc))
+
+
+def check_batched(wl, stats, failures, batched_pool):
+    for (mode, gs, dtype), items in batched_pool.items():
+        outs = wl.compress_weights_packed_batched([it[0] for it in items], _cfg(mode, gs), want_e8m0=mode == "mxfp4")
+        for (w, w32, rc, rs, rz, desc), cw in zip(items, outs):
+            got = host(cw.tensor).reshape(-1)
+            if mode in FLOAT_MODES:  # the build's 4-bit codes: LUT[code] == the reference's value
+                lut = O.NF4_QUANTILES if mode == "nf4" else O.E2M1_VALUE_OF_CODE
+                got = lut[np.stack([got & 15, got >> 4], axis=1).reshape(-1)]
+                ref = rc
+            elif mode == "int4_asym":
+                ref = O.pack_uint4(rc)
+            elif mode == "int4_sym":
+                ref = O.pack_int4(rc)
+            else:
+                ref = rc
+            ok = _same(got, np.asarray(ref).reshape(-1)) and _same(host(cw.scale).reshape(-1), rs.reshape(-1))
+            if rz is not None:
+                ok = ok and _same(host(cw.zero_point).reshape(-1), rz.reshape(-1))
+            stats["batched"] += 1
+            if not ok:
+                failures.append("batched " + desc)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=1000)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    from nncf_amd import weight_lowering as wl
+    rng = np.random.default_rng(args.seed)
+    stats = {"single": 0, "batched": 0, "given": 0, "qdq": 0}
+    failures, pool = [], {}
+    t0 = time.time()
+    for i in range(args.cases):
+        check_case(rng, wl, stats, failures, pool)
+        if (i + 1) % 200 == 0:
+            check_batched(wl, stats, failures, pool)
+            pool = {}
+            print(f"[{i + 1}/{args.cases}] {stats} failures {len(failures)}  {time.time() - t0:.0f}s", flush=True)
+    check_batched(wl, stats, failures, pool)
+    torch.cuda.synchronize()
+    for f in failures[:50]:
+        print("MISMATCH", f)
+    print(json.dumps({"seed": args.seed, "cases": args.cases, **stats, "mismatches": len(failures)}))
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
