@@ -153,11 +153,47 @@ def check_batched(wl, stats, failures, batched_pool):
                 failures.append("batched " + desc)
 
 
+def check_reducers(rng, n_cases, failures):
+    """activation_stats (token mean + the four mixed-precision statistics) on random [batch, tokens, hidden] against
+    float64 / the oracle's reducers, at the tolerances of tests/test_gpu_reducers.py; mean-only call = same bits."""
+    from nncf_amd import statistics as S
+    for _ in range(n_cases):
+        dtype = str(rng.choice(["f32", "bf16", "f16"]))
+        hidden = int(rng.choice([int(rng.integers(1, 700)), 8 * int(rng.integers(1, 300)), 4096, 5120]))
+        tokens = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(200, 3000)), 256, 2048]))
+        batch = int(rng.choice([1, 1, 1, 2, 5]))
+        x32 = rng.standard_normal((batch, tokens, hidden)).astype(np.float32) * np.float32(10.0 ** rng.uniform(-2, 1))
+        x32[..., int(rng.integers(0, hidden))] += np.float32(rng.uniform(-200, 200))  # a channel with a large mean
+        x = to_dev(x32, dtype)
+        xr = host(x).astype(np.float32)
+        mean, stats = S.activation_stats(x)
+        only, _ = S.activation_stats(x, want_stats=False)
+        rt = 3e-6 if dtype == "f32" else 2 ** -7
+        x64 = xr.astype(np.float64)
+        try:
+            assert torch.equal(only, mean), "mean-only bits"
+            np.testing.assert_allclose(host(mean), x64.mean(axis=(0, 1)), rtol=3e-6, atol=5e-6 * max(1.0, np.abs(x64).max()))
+            np.testing.assert_allclose(float(stats[0]), O.mean_variance_reducer(xr, (1,), dtype), rtol=max(rt, 1e-4))
+            np.testing.assert_allclose(float(stats[1]), O.max_variance_reducer(xr, (1,), dtype), rtol=max(rt, 1e-4))
+            np.testing.assert_allclose(float(stats[2]), O.mean_abs_max_reducer(xr, (1,)), rtol=3e-6)
+            np.testing.assert_allclose(float(stats[3]), np.sum(x64 ** 2), rtol=1e-5)
+        except AssertionError as e:
+            failures.append(f"reducers {dtype} {(batch, tokens, hidden)}: {str(e).strip().splitlines()[-1][:120]}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--reducers", type=int, default=0, help="cases of the activation-statistics reducer instead")
     args = ap.parse_args()
+    if args.reducers:
+        failures = []
+        check_reducers(np.random.default_rng(args.seed), args.reducers, failures)
+        for f in failures[:50]:
+            print("MISMATCH", f)
+        print(json.dumps({"seed": args.seed, "reducer_cases": args.reducers, "mismatches": len(failures)}))
+        return 1 if failures else 0
     from nncf_amd import weight_lowering as wl
     rng = np.random.default_rng(args.seed)
     stats = {"single": 0, "batched": 0, "given": 0, "qdq": 0}
