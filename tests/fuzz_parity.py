@@ -181,12 +181,45 @@ def check_reducers(rng, n_cases, failures):
             failures.append(f"reducers {dtype} {(batch, tokens, hidden)}: {str(e).strip().splitlines()[-1][:120]}")
 
 
+def check_error_metric(rng, n_cases, failures):
+    """get_integer_quantization_error[s] (per weight and batched; grouped and whole-row groups) against the oracle at
+    the reference's rtol 1e-4."""
+    from nncf_amd import weight_lowering as wl
+    pool = {}
+    for _ in range(n_cases):
+        mode = str(rng.choice(INT_MODES))
+        dtype = str(rng.choice(["f32", "bf16", "f16"]))
+        gs = int(rng.choice([-1, -1, 8, 16, 32, 64, 128, 24]))
+        rows = int(rng.integers(1, 120))
+        cols = (int(rng.choice([int(rng.integers(1, 300)), 8 * int(rng.integers(1, 600)), 4096, 14336])) if gs == -1
+                else gs * int(rng.integers(1, max(2, 4096 // gs))))
+        w32 = representable(rng.standard_normal((rows, cols)).astype(np.float32) * np.float32(10.0 ** rng.uniform(-3, 1)), dtype)
+        pool.setdefault((mode, gs, dtype), []).append(w32)
+    for (mode, gs, dtype), ws32 in pool.items():
+        ws = [to_dev(w, dtype) for w in ws32]
+        for reduction in ("max_mean", "frobenius"):
+            got = wl.get_integer_quantization_errors(ws, [(1,)] * len(ws), _cfg(mode, gs), reduction)
+            for i, w32 in enumerate(ws32):
+                ref = O.get_integer_quantization_error(w32, (1,), mode, gs, reduction)
+                one = wl.get_integer_quantization_error(ws[i], (1,), _cfg(mode, gs), reduction) if i % 3 == 0 else got[i]
+                if not (np.isclose(got[i], ref, rtol=1e-4, atol=1e-12) and np.isclose(one, ref, rtol=1e-4, atol=1e-12)):
+                    failures.append(f"error metric {mode} g{gs} {dtype} {w32.shape} {reduction}: {got[i]} / {one} vs {ref}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--reducers", type=int, default=0, help="cases of the activation-statistics reducer instead")
+    ap.add_argument("--errors", type=int, default=0, help="cases of the quantization-error metric instead")
     args = ap.parse_args()
+    if args.errors:
+        failures = []
+        check_error_metric(np.random.default_rng(args.seed), args.errors, failures)
+        for f in failures[:50]:
+            print("MISMATCH", f)
+        print(json.dumps({"seed": args.seed, "error_metric_cases": args.errors, "mismatches": len(failures)}))
+        return 1 if failures else 0
     if args.reducers:
         failures = []
         check_reducers(np.random.default_rng(args.seed), args.reducers, failures)
