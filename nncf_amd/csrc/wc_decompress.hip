@@ -38,6 +38,12 @@ __device__ __forceinline__ void store8(void* out, int64_t e0, const float* v) {
     }
 }
 
+// E8M0 scale byte -> 2^(byte - 127): byte 0 is the subnormal 2^-127, byte 255 stays +inf (the format's NaN code is
+// never written by the lowering)
+__device__ __forceinline__ float e8m0_scale(uint32_t byte) {
+    return __builtin_bit_cast(float, byte ? byte << 23 : 0x00400000u);
+}
+
 // one thread = 8 consecutive elements of one group (group_size % 8 == 0)
 template <int OUT_DT>
 __global__ __launch_bounds__(256) void k_decompress8(const uint8_t* __restrict__ codes, int mode, int64_t n_elems, int64_t gs,
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(256) void k_decompress8(const uint8_t* __restrict__
     const int64_t g = e0 / gs;
     float s;
     if (scale_kind == kScaleF16) s = (float)__builtin_bit_cast(_Float16, ((const uint16_t*)scale)[g]);
-    else if (scale_kind == kScaleE8M0) s = __builtin_bit_cast(float, (uint32_t)((const uint8_t*)scale)[g] << 23);  // 2^(byte - 127)
+    else if (scale_kind == kScaleE8M0) s = e8m0_scale(((const uint8_t*)scale)[g]);
     else s = ((const float*)scale)[g];
     float d[8];
     const bool four = mode >= NNCF_AMD_INT4_ASYM;
@@ -134,9 +140,12 @@ __global__ __launch_bounds__(256) void k_decompress_h(const uint8_t* __restrict_
     const uint64_t e0 = v * 8;
     float r[8];
     if constexpr (MODE == NNCF_AMD_MXFP4) {
-        // scale 2^(byte - 127) times the 2^14 of the code's fp16 image; byte 0 stays the zero it is in k_decompress8
+        // scale 2^(byte - 127) times the 2^14 of the code's fp16 image: one exact power of two while it is finite
+        // (byte <= 240); the few bytes above take the two factors one after the other
         const uint32_t byte = ((const uint8_t*)scale)[g];
-        const float s = __builtin_bit_cast(float, byte << 23) * 16384.0f;
+        const bool wide = byte > 240u;
+        const float s = wide ? e8m0_scale(byte) : __builtin_bit_cast(float, (byte + 14u) << 23);
+        const float pre = wide ? 16384.0f : 1.0f;
         const uint32_t p = *(const uint32_t*)(codes + e0 / 2);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -144,6 +153,15 @@ __global__ __launch_bounds__(256) void k_decompress_h(const uint8_t* __restrict_
             const h2 h = __builtin_bit_cast(h2, ((q & 0x00070007u) << 9) | ((q & 0x00080008u) << 12));
             r[k] = (float)h.x * s;
             r[k + 4] = (float)h.y * s;
+        }
+        if (wide) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t q = p >> (4 * k);
+                const h2 h = __builtin_bit_cast(h2, ((q & 0x00070007u) << 9) | ((q & 0x00080008u) << 12));
+                r[k] = ((float)h.x * pre) * s;
+                r[k + 4] = ((float)h.y * pre) * s;
+            }
         }
     } else {
         const _Float16 s = __builtin_bit_cast(_Float16, ((const uint16_t*)scale)[g]);
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(256) void k_decompress1(const uint8_t* __restrict__
     const int64_t g = e / gs;
     float s;
     if (scale_kind == kScaleF16) s = (float)__builtin_bit_cast(_Float16, ((const uint16_t*)scale)[g]);
-    else if (scale_kind == kScaleE8M0) s = __builtin_bit_cast(float, (uint32_t)((const uint8_t*)scale)[g] << 23);
+    else if (scale_kind == kScaleE8M0) s = e8m0_scale(((const uint8_t*)scale)[g]);
     else s = ((const float*)scale)[g];
     float d;
     if (mode >= NNCF_AMD_INT4_ASYM) {
@@ -235,6 +253,8 @@ __global__ __launch_bounds__(256) void k_decompress1(const uint8_t* __restrict__
     float prod = d * s;
     if (scale_kind == kScaleF16) {
         if (mode == NNCF_AMD_NF4) prod = (float)(_Float16)d * s;
+        // (kept from fusing into a multiply-add with the conversion: d * s + 0 loses the sign of a zero product)
+        asm volatile("" : "+v"(prod));
         prod = (float)(_Float16)prod;
     }
     if constexpr (OUT_DT == NNCF_AMD_F32) ((float*)out)[e] = prod;

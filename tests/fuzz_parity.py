@@ -206,13 +206,72 @@ def check_error_metric(rng, n_cases, failures):
                     failures.append(f"error metric {mode} g{gs} {dtype} {w32.shape} {reduction}: {got[i]} / {one} vs {ref}")
 
 
+def check_decompress(rng, n_cases, failures):
+    """The decompressor forward on random codes / scales / zero points against the reference's op chain in torch
+    (layers.py decompress_symmetric / _asymmetric, fp16 arithmetic; NF4 / e2m1 look-up times scale): bit-exact, fp16
+    scales over their whole range (subnormals, products that overflow), any even group size."""
+    from nncf_amd import decompressors as D
+    from tests.test_gpu_decompress import _unpack_uint4
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 2 ** 31)))
+    e2m1 = torch.tensor([0, 0.5, 1, 1.5, 2, 3, 4, 6, -0.0, -0.5, -1, -1.5, -2, -3, -4, -6], device="cuda")
+    nf4 = torch.tensor(O.NF4_QUANTILES, device="cuda", dtype=torch.float32)
+    for _ in range(n_cases):
+        mode = str(rng.choice(INT_MODES + FLOAT_MODES))
+        out_dtype = [torch.float16, torch.bfloat16, torch.float32][int(rng.integers(0, 3))]
+        gs = 32 if mode == "mxfp4" else int(rng.choice([2 * int(rng.integers(1, 80)), 8 * int(rng.integers(1, 600)), 32, 64, 128, 4096]))
+        n_groups = int(rng.choice([int(rng.integers(1, 50)), int(rng.integers(50, 20000))]))
+        if n_groups * gs > 1 << 25:
+            n_groups = max(1, (1 << 25) // gs)
+        four = not mode.startswith("int8")
+        n = n_groups * gs
+        codes = torch.randint(0, 256, (n // 2 if four else n,), dtype=torch.uint8, device="cuda", generator=g)
+        if mode == "mxfp4":
+            scale = torch.randint(1, 255, (n_groups,), dtype=torch.uint8, device="cuda", generator=g)
+        else:  # any finite fp16 bit pattern, both signs
+            bits = torch.randint(0, 0x7c00, (n_groups,), dtype=torch.int32, device="cuda", generator=g)
+            sign = torch.randint(0, 2, (n_groups,), dtype=torch.int32, device="cuda", generator=g) << 15
+            scale = (bits | sign).to(torch.int16).view(torch.float16)
+        zp = None
+        if mode == "int4_asym":
+            zp = torch.randint(0, 256, ((n_groups + 1) // 2,), dtype=torch.uint8, device="cuda", generator=g)
+        if mode == "int8_asym":
+            zp = torch.randint(0, 256, (n_groups,), dtype=torch.uint8, device="cuda", generator=g)
+        got = D.decompress(codes, mode, n_groups, gs, scale, zp, out_dtype)
+        c = _unpack_uint4(codes).reshape(n_groups, gs) if four else codes.reshape(n_groups, gs)
+        if mode == "mxfp4":
+            ref = e2m1[c.long()] * torch.exp2(scale.float() - 127).unsqueeze(1)
+        elif mode == "nf4":
+            ref = nf4[c.long()].to(torch.float16) * scale.unsqueeze(1)
+        elif mode == "int4_sym":
+            ref = (c.to(torch.float16) - 8) * scale.unsqueeze(1)
+        elif mode == "int4_asym":
+            z = _unpack_uint4(zp).reshape(-1)[:n_groups]
+            ref = (c.to(torch.float16) - z.to(torch.float16).unsqueeze(1)) * scale.unsqueeze(1)
+        elif mode == "int8_asym":
+            ref = (c.to(torch.float16) - zp.to(torch.float16).unsqueeze(1)) * scale.unsqueeze(1)
+        else:
+            ref = c.view(torch.int8).to(torch.float16) * scale.unsqueeze(1)
+        ref = ref.reshape(-1).to(out_dtype)
+        same = (got == ref) | (got.isnan() & ref.isnan())
+        if not bool(same.all()) or not torch.equal(torch.signbit(got), torch.signbit(ref)):
+            failures.append(f"decompress {mode} g{gs} x {n_groups} -> {out_dtype}: {int((~same).sum())} values differ")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--reducers", type=int, default=0, help="cases of the activation-statistics reducer instead")
     ap.add_argument("--errors", type=int, default=0, help="cases of the quantization-error metric instead")
+    ap.add_argument("--decompress", type=int, default=0, help="cases of the decompressor forward instead")
     args = ap.parse_args()
+    if args.decompress:
+        failures = []
+        check_decompress(np.random.default_rng(args.seed), args.decompress, failures)
+        for f in failures[:50]:
+            print("MISMATCH", f)
+        print(json.dumps({"seed": args.seed, "decompress_cases": args.decompress, "mismatches": len(failures)}))
+        return 1 if failures else 0
     if args.errors:
         failures = []
         check_error_metric(np.random.default_rng(args.seed), args.errors, failures)

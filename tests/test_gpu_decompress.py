@@ -162,3 +162,55 @@ def test_flat_decompress_group_indexing(mode, gs, n_groups, out_dtype):
     else:
         ref = c.view(torch.int8).to(torch.float16) * scale.unsqueeze(1)
     assert torch.equal(got, ref.reshape(-1).to(out_dtype))
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_mxfp4_every_code_under_every_scale_byte(out_dtype):
+    """e2m1 value * 2^(byte - 127) rounded once to the output dtype, for all 16 codes and the scale bytes 0 (the
+    subnormal 2^-127) ... 254 (2^127: the code's fp16 image times 2^14 must not be folded into an overflowing
+    scale); found by the randomized campaign (tests/fuzz_parity.py --decompress)."""
+    from nncf_amd import decompressors as D
+    vals = np.array([0, 0.5, 1, 1.5, 2, 3, 4, 6, -0.0, -0.5, -1, -1.5, -2, -3, -4, -6], dtype=np.float64)
+    group = np.concatenate([np.arange(16, dtype=np.uint8)] * 2)
+    packed = (group[0::2] | (group[1::2] << 4)).astype(np.uint8)
+    n_groups = 255
+    codes = torch.from_numpy(np.tile(packed, n_groups)).cuda()
+    scale = torch.arange(n_groups, dtype=torch.int32).to(torch.uint8).cuda()
+    exact = vals[group][None, :] * np.exp2(np.arange(n_groups, dtype=np.float64) - 127)[:, None]
+    ref = torch.from_numpy(exact).to(out_dtype)
+    for gs_groups in ((32, n_groups),):
+        got = D.decompress(codes, "mxfp4", gs_groups[1], gs_groups[0], scale, None, out_dtype).reshape(n_groups, 32).cpu()
+        assert torch.equal(got, ref) and torch.equal(torch.signbit(got), torch.signbit(ref))
+
+
+@pytest.mark.parametrize("mode,gs", [("int8_asym", 106), ("int4_asym", 110), ("int8_sym", 50), ("int4_sym", 8), ("int8_asym", 64)])
+def test_zero_products_keep_the_sign_of_the_scale(mode, gs):
+    """(c - z) * s with c == z and a negative fp16 scale is -0.0 in the reference's op chain, for every kernel
+    (group sizes that are not multiples of 8 take the per-element kernel) and output dtype."""
+    from nncf_amd import decompressors as D
+    g = torch.Generator(device="cuda").manual_seed(gs)
+    n_groups = 64
+    four = mode.startswith("int4")
+    n = n_groups * gs
+    codes = torch.randint(0, 256, (n // 2 if four else n,), dtype=torch.uint8, device="cuda", generator=g)
+    scale = -(torch.rand(n_groups, device="cuda", generator=g) * 0.02 + 1e-4).to(torch.float16)
+    zp = None
+    if mode == "int4_asym":
+        zp = torch.randint(0, 256, ((n_groups + 1) // 2,), dtype=torch.uint8, device="cuda", generator=g)
+    if mode == "int8_asym":
+        zp = torch.randint(0, 256, (n_groups,), dtype=torch.uint8, device="cuda", generator=g)
+    c = _unpack_uint4(codes).reshape(n_groups, gs) if four else codes.reshape(n_groups, gs)
+    if mode == "int4_sym":
+        ref = (c.to(torch.float16) - 8) * scale.unsqueeze(1)
+    elif mode == "int4_asym":
+        z = _unpack_uint4(zp).reshape(-1)[:n_groups]
+        ref = (c.to(torch.float16) - z.to(torch.float16).unsqueeze(1)) * scale.unsqueeze(1)
+    elif mode == "int8_asym":
+        ref = (c.to(torch.float16) - zp.to(torch.float16).unsqueeze(1)) * scale.unsqueeze(1)
+    else:
+        ref = c.view(torch.int8).to(torch.float16) * scale.unsqueeze(1)
+    assert bool((ref == 0).any())
+    for out_dtype in (torch.float16, torch.bfloat16, torch.float32):
+        got = D.decompress(codes, mode, n_groups, gs, scale, zp, out_dtype)
+        want = ref.reshape(-1).to(out_dtype)
+        assert torch.equal(got, want) and torch.equal(torch.signbit(got), torch.signbit(want))
