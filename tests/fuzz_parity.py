@@ -19,6 +19,7 @@ import torch
 from oracle import wc_oracle as O
 from tests.gpu_utils import host, representable, to_dev
 
+WIDE = False  # --wide: magnitudes over the whole fp32 range (subnormal groups, sums that overflow)
 INT_MODES = ["int8_asym", "int8_sym", "int4_asym", "int4_sym"]
 FLOAT_MODES = ["nf4", "mxfp4"]
 
@@ -37,11 +38,31 @@ def _same(a, b):
     return bool((a == b).all())
 
 
+def _diagnose(w32, codes, rc, scale, rs, zp, rz):
+    out = f" | max|w| {np.abs(w32).max():.3e} min|w|>0 {np.abs(w32[w32 != 0]).min() if (w32 != 0).any() else 0:.3e}"
+    bad_s = ~((scale == rs) | (np.isnan(scale) & np.isnan(rs)))
+    out += f" | scale mismatches {int(bad_s.sum())}"
+    if bad_s.any():
+        i = tuple(np.argwhere(bad_s)[0])
+        out += f" first got {scale[i]!r} ref {rs[i]!r}"
+    if zp is not None:
+        out += f" | zp mismatches {int((zp != rz).sum())}"
+    if codes.shape == rc.shape:
+        bad_c = ~((codes == rc) | ((codes != codes) & (rc != rc)))
+        out += f" | code mismatches {int(bad_c.sum())} of {rc.size}"
+        if bad_c.any():
+            i = tuple(np.argwhere(bad_c)[0])
+            wv = w32.reshape(rc.shape)[i]
+            si = tuple(list(i[:-1]) + [0])
+            out += f" first w {wv!r} got {codes[i]!r} ref {rc[i]!r} scale {rs[si]!r}"
+    return out
+
+
 def random_values(rng, shape):
     """One of several distributions: plain normal at a random magnitude, outlier channels, constant / zero groups,
     values on and next to rounding ties, a wide dynamic range."""
     kind = rng.integers(0, 7)
-    mag = np.float32(10.0 ** rng.uniform(-6, 3))
+    mag = np.float32(10.0 ** (rng.uniform(-42, 37) if WIDE else rng.uniform(-6, 3)))
     w = rng.standard_normal(shape).astype(np.float32) * mag
     if kind == 1:  # outlier columns
         idx = rng.integers(0, shape[-1], max(1, shape[-1] // 50))
@@ -62,7 +83,8 @@ def random_values(rng, shape):
         w = w * np.float32(10.0) ** rng.uniform(-3, 3, shape).astype(np.float32)
     elif kind == 5:  # all positive / all negative rows (asymmetric zero points at the range ends)
         w = np.abs(w) * (np.float32(1.0) if rng.random() < 0.5 else np.float32(-1.0))
-    return w.astype(np.float32)
+    with np.errstate(all="ignore"):  # finite weights only: inf / NaN weights are outside the contract
+        return np.clip(np.nan_to_num(w.astype(np.float32), nan=0.0), -3.0e38, 3.0e38).astype(np.float32)
 
 
 def random_case(rng):
@@ -96,8 +118,11 @@ def check_case(rng, wl, stats, failures, batched_pool):
     cw = wl.compress_weight(w, (axis,), _cfg(mode, gs))
     ok = _same(host(cw.tensor), rc) and _same(host(cw.scale), rs) and (rz is None or _same(host(cw.zero_point), rz))
     stats["single"] += 1
-    if not ok:
-        failures.append("single " + desc)
+    if not ok and not np.isfinite(w32).all():
+        stats["nonfinite_skipped"] = stats.get("nonfinite_skipped", 0) + 1  # inf / NaN weights: outside the contract
+    elif not ok:
+        failures.append("single " + desc + _diagnose(w32, host(cw.tensor), rc, host(cw.scale), rs,
+                                                     None if rz is None else host(cw.zero_point), rz))
     # the same weight against GIVEN parameters (another tensor's scale, perturbed): the path scale estimation, AWQ
     # and GPTQ results take into the lowering; and the quantize-dequantize form
     from nncf_amd.parameters import CompressedWeight
@@ -150,7 +175,19 @@ def check_batched(wl, stats, failures, batched_pool):
                 ok = ok and _same(host(cw.zero_point).reshape(-1), rz.reshape(-1))
             stats["batched"] += 1
             if not ok:
-                failures.append("batched " + desc)
+                extra = ""
+                if np.isfinite(w32).all():
+                    refv = np.asarray(ref).reshape(-1)
+                    bad = ~((got == refv) | ((got != got) & (refv != refv))) if got.shape == refv.shape else None
+                    if bad is not None and bad.any() and mode in FLOAT_MODES:
+                        i = int(np.argwhere(bad)[0][0])
+                        extra = (f" | {int(bad.sum())} of {bad.size} values differ; first w {w32.reshape(-1)[i]!r} got {got[i]!r} "
+                                 f"ref {refv[i]!r} scale {rs.reshape(-1)[i // gs]!r} group max {np.abs(w32.reshape(-1, gs)[i // gs]).max()!r}")
+                    sb = host(cw.scale).reshape(-1) != rs.reshape(-1)
+                    extra += f" | scale mismatches {int(sb.sum())}"
+                    failures.append("batched " + desc + extra)
+                else:
+                    stats["nonfinite_skipped"] = stats.get("nonfinite_skipped", 0) + 1
 
 
 def check_reducers(rng, n_cases, failures):
@@ -264,7 +301,10 @@ def main():
     ap.add_argument("--reducers", type=int, default=0, help="cases of the activation-statistics reducer instead")
     ap.add_argument("--errors", type=int, default=0, help="cases of the quantization-error metric instead")
     ap.add_argument("--decompress", type=int, default=0, help="cases of the decompressor forward instead")
+    ap.add_argument("--wide", action="store_true", help="weight magnitudes over the whole fp32 range")
     args = ap.parse_args()
+    global WIDE
+    WIDE = args.wide
     if args.decompress:
         failures = []
         check_decompress(np.random.default_rng(args.seed), args.decompress, failures)
