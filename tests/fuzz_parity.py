@@ -294,6 +294,43 @@ def check_decompress(rng, n_cases, failures):
             failures.append(f"decompress {mode} g{gs} x {n_groups} -> {out_dtype}: {int((~same).sum())} values differ")
 
 
+def check_misc(rng, n_cases, failures):
+    """Nibble packing / unpacking, integer dequantization and the token means of a list of samples."""
+    from nncf_amd import statistics as S, weight_lowering as wl
+    from nncf_amd.parameters import CompressedWeight
+    for _ in range(n_cases):
+        n = 2 * int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(40, 100000))]))
+        u = rng.integers(0, 16, n).astype(np.uint8)
+        i4 = rng.integers(-8, 8, n).astype(np.int8)
+        pu, pi = wl.pack_uint4(torch.from_numpy(u).cuda()), wl.pack_int4(torch.from_numpy(i4).cuda())
+        if not (_same(host(pu).reshape(-1), O.pack_uint4(u).reshape(-1)) and _same(host(pi).reshape(-1), O.pack_int4(i4).reshape(-1))):
+            failures.append(f"pack n={n}")
+        if not (_same(host(wl.unpack_uint4(pu)).reshape(-1), u) and _same(host(wl.unpack_int4(pi)).reshape(-1), i4)):
+            failures.append(f"unpack n={n}")
+        # dequantization of grouped codes
+        mode = str(rng.choice(INT_MODES))
+        gs = int(rng.choice([4, 16, 24, 128]))
+        rows, groups = int(rng.integers(1, 60)), int(rng.integers(1, 20))
+        w32 = (rng.standard_normal((rows, groups * gs)) * 10.0 ** rng.uniform(-4, 2)).astype(np.float32)
+        rc, rs, rz = O.compress_weight(w32, (1,), mode, gs)
+        cw = CompressedWeight(torch.from_numpy(rc).cuda(), torch.from_numpy(rs).cuda(), None if rz is None else torch.from_numpy(rz).cuda())
+        if not _same(host(wl.do_integer_dequantization(cw, 1)), O.do_integer_dequantization(rc, rs, rz, 1)):
+            failures.append(f"dequantize {mode} g{gs} {(rows, groups * gs)}")
+        # token means of a ragged list of samples
+        dtype = str(rng.choice(["f32", "bf16", "f16"]))
+        hidden = int(rng.choice([int(rng.integers(1, 300)), 8 * int(rng.integers(1, 200)), 4096]))
+        counts = [int(rng.choice([1, int(rng.integers(1, 70)), int(rng.integers(70, 1500))])) for _ in range(int(rng.integers(2, 80)))]
+        xs32 = [(rng.standard_normal((1, t, hidden)) + rng.standard_normal(hidden) * 5).astype(np.float32) for t in counts]
+        xs = [to_dev(x, dtype) for x in xs32]
+        got = S.activations_to_wc_statistics(xs)
+        tol = 1e-6 if dtype == "f32" else (8e-3 if dtype == "bf16" else 1e-3)
+        for x, m in zip(xs, got.mean_values):
+            ref = host(x).astype(np.float64).reshape(-1, hidden).mean(0)
+            if not np.allclose(host(m).astype(np.float64), ref, rtol=tol, atol=tol * max(1e-30, np.abs(ref).max())):
+                failures.append(f"token means {dtype} hidden {hidden} tokens {x.shape[1]} of {len(xs)} samples")
+                break
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=1000)
@@ -302,7 +339,15 @@ def main():
     ap.add_argument("--errors", type=int, default=0, help="cases of the quantization-error metric instead")
     ap.add_argument("--decompress", type=int, default=0, help="cases of the decompressor forward instead")
     ap.add_argument("--wide", action="store_true", help="weight magnitudes over the whole fp32 range")
+    ap.add_argument("--misc", type=int, default=0, help="cases of pack / unpack / dequantize / token means instead")
     args = ap.parse_args()
+    if args.misc:
+        failures = []
+        check_misc(np.random.default_rng(args.seed), args.misc, failures)
+        for f in failures[:50]:
+            print("MISMATCH", f)
+        print(json.dumps({"seed": args.seed, "misc_cases": args.misc, "mismatches": len(failures)}))
+        return 1 if failures else 0
     global WIDE
     WIDE = args.wide
     if args.decompress:
