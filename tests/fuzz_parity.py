@@ -407,6 +407,25 @@ def check_gptq(rng, n_cases, failures):
             failures.append(desc + ": zero points differ")
 
 
+def check_hessian(rng, n_cases, failures):
+    """gptq.calculate_hessian on random lists of calibration items (ragged token counts, every kernel: fp32 MFMA,
+    16-bit 128- and 256-tile kernels, the item-list form, odd K) against float64 at the bar of test_hessian_vs_float64."""
+    from nncf_amd import gptq
+    for _ in range(n_cases):
+        dtype = str(rng.choice(["f32", "bf16", "f16"]))
+        K = int(rng.choice([int(rng.integers(1, 400)), 8 * int(rng.integers(1, 200)), 2048 + 8 * int(rng.integers(0, 150)),
+                            2048 + int(rng.integers(0, 600))]))
+        n_items = int(rng.integers(1, 12))
+        xs32 = [rng.standard_normal((1, int(rng.choice([1, int(rng.integers(1, 100)), int(rng.integers(100, 1200))])), K)).astype(np.float32)
+                for _i in range(n_items)]
+        xs = [to_dev(x, dtype) for x in xs32]
+        H = host(gptq.calculate_hessian(xs))[0]
+        ref = sum(host(x).astype(np.float64)[0].T @ host(x).astype(np.float64)[0] for x in xs) * (2.0 / n_items)
+        if not np.allclose(H, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max()):
+            err = np.abs(H - ref).max() / np.abs(ref).max()
+            failures.append(f"hessian {dtype} K={K} tokens {[x.shape[1] for x in xs32]}: max error {err:.2e} of max|H|")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=1000)
@@ -418,7 +437,15 @@ def main():
     ap.add_argument("--misc", type=int, default=0, help="cases of pack / unpack / dequantize / token means instead")
     ap.add_argument("--data-aware", type=int, default=0, help="cases of scale estimation / AWQ instead")
     ap.add_argument("--gptq", type=int, default=0, help="cases of the GPTQ sweep with a given inverse-Hessian factor instead")
+    ap.add_argument("--hessian", type=int, default=0, help="cases of the Hessian accumulation instead")
     args = ap.parse_args()
+    if args.hessian:
+        failures = []
+        check_hessian(np.random.default_rng(args.seed), args.hessian, failures)
+        for f in failures[:50]:
+            print("MISMATCH", f)
+        print(json.dumps({"seed": args.seed, "hessian_cases": args.hessian, "mismatches": len(failures)}))
+        return 1 if failures else 0
     if args.gptq:
         failures = []
         check_gptq(np.random.default_rng(args.seed), args.gptq, failures)
