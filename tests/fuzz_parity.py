@@ -141,6 +141,16 @@ def check_case(rng, wl, stats, failures, batched_pool):
             ref = O.pack_uint4(rc2) if mode == "int4_asym" else O.pack_int4(rc2)
             if not _same(host(packed.tensor).reshape(-1), np.asarray(ref).reshape(-1)):
                 failures.append("given-parameters packed " + desc)
+    if mode in FLOAT_MODES and rng.random() < 0.5:
+        # a given scale (what scale estimation hands to the NF4 lowering); a power-of-two factor for the MX format
+        factor = np.float32(2.0 ** rng.integers(-2, 3)) if mode == "mxfp4" else np.float32(rng.uniform(0.3, 3.0))
+        gscale = (rs * factor).astype(np.float32)
+        if np.isfinite(gscale).all() and (gscale != 0).all():
+            rv2, _, _ = O.compress_weight(w32, (axis,), mode, gs, gscale)
+            cw2 = wl.compress_weight(w, (axis,), _cfg(mode, gs), CompressedWeight(None, torch.from_numpy(gscale).cuda()))
+            stats["given"] += 1
+            if not _same(host(cw2.tensor), rv2):
+                failures.append("given-scale " + desc)
     if rng.random() < 0.3:
         if mode in INT_MODES:
             dq = wl.integer_quantize_dequantize_weight(w, _cfg(mode, gs), (axis,))
