@@ -10,9 +10,12 @@ group_size=128, through the C ABI (nncf_amd_int_quantize_batched).  Metric: GB/s
 (input bytes of the WHOLE model / wall time of the slowest rank).  N > 1: one process per GPU (torchrun); the
 model's tensor list is cut by longest-processing-time-first (nncf_amd.distributed.partition_lpt, the partition the
 product uses), every rank creates and compresses ONLY its shard, no data-path collective: strong scaling of one
-model ("wall time of Llama-3-8B / 70B at 1/2/4/8 GPUs" = ms_per_step).  --gather adds the RCCL all-gather that
-assembles the compressed payload on every rank and reports it separately; --scaling weak gives every rank a whole
-model of its own instead (round-1 behaviour).
+model ("wall time of Llama-3-8B / 70B at 1/2/4/8 GPUs" = ms_per_step).  Without a launcher, `--gpus N` starts the
+N rank processes itself (launch_ranks); under torchrun the ranks are already there.  For N > 1 the RCCL all-gather
+that assembles the compressed payload on every rank is always timed as well: `value` is without it,
+`value_gathered` with it, `ranks_seen` is what an all-reduce of 1 returns.  Mixtral workloads place expert e on rank
+e % N; --scaling weak gives every rank a whole model of its own instead (round-1 behaviour).  After the
+timed region the same step runs back to back for >= 2 s (`sustained_ms_per_step`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -150,6 +153,74 @@ def cpu_baseline(geometry, mode, gs, budget_s=12.0):
                       f"g{gs}, {passes} passes, {t_total:.1f}s of CPU work on {threads} threads"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one GPU each, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set as torchrun would), pass rank 0's JSON line through, fail if any rank fails.  Runs
+    before anything in this process touches the GPU (no HIP call, no torch.cuda query that initialises it)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NNCF_AMD_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
+        sys.exit(1)
+    sys.exit(0)
+
+
+def shard_of(model, n_shapes, world, placement):
+    """Indices into `model` per rank; within a rank the reference's order, largest weight first
+    (algorithm.py:1198-1200), ties by position."""
+    from nncf_amd.distributed import partition_by_expert, partition_lpt
+
+    if placement == "expert":  # the three matrices of expert e (every layer) on rank e % N
+        parts = partition_by_expert([(k % n_shapes) // 3 for k, _ in model], world)
+    else:
+        parts = partition_lpt([o * i for _, (o, i) in model], world)
+    return [sorted(p, key=lambda k: (-model[k][1][0] * model[k][1][1], k)) for p in parts]
+
+
+def dry_run(args):
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    geometry, mode, gs = WORKLOADS[args.workload]
+    shapes, n_layers = SHAPES[geometry]
+    n_layers = args.layers or n_layers
+    model = [(layer * len(shapes) + j, sh) for layer in range(n_layers) for j, sh in enumerate(shapes)]
+    placement = ("expert" if geometry.startswith("mixtral") else "lpt") if args.placement == "auto" else args.placement
+    parts = shard_of(model, len(shapes), world, placement)
+    seen = 1
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        seen = int(one.item())
+        mine = torch.tensor([sum(model[k][1][0] * model[k][1][1] for k in parts[rank])], dtype=torch.int64)
+        dist.all_reduce(mine)
+        assert int(mine.item()) == sum(o * i for _, (o, i) in model)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "placement": placement,
+                          "tensors_per_rank": [len(p) for p in parts],
+                          "elements_per_rank": [sum(model[k][1][0] * model[k][1][1] for k in p) for p in parts],
+                          "launcher": "bench.py --gpus N (own rank processes)"
+                          if os.environ.get("NNCF_AMD_BENCH_SPAWNED") else "external (torchrun)"}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,11 +228,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="llama3-8b-int4sym-g128", choices=sorted(WORKLOADS))
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug)")
-    ap.add_argument("--gather", action="store_true", help="also time an RCCL all-gather of the compressed payload")
+    ap.add_argument("--gather", action="store_true", help="(kept for old command lines: N > 1 always times the gather)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: ONE model sharded over the ranks (default); weak: a whole model per rank")
+    ap.add_argument("--placement", choices=["auto", "lpt", "expert"], default="auto",
+                    help="tensor -> rank: LPT on the element count, or expert e -> rank e %% N (auto: expert for the "
+                         "mixtral workloads, SURVEY 8e)")
+    ap.add_argument("--sustained-s", type=float, default=2.0, help="seconds of back-to-back steps after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only (no GPU): the ranks connect over gloo, count themselves and rank 0 prints "
+                         "the partition it would run -- checks the launcher and the placement on a CPU-only host")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus, sys.argv[1:])  # does not return
+    if args.dry_run:
+        return dry_run(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -189,19 +272,34 @@ def main():
     n_layers = args.layers or n_layers
     model = [(layer * len(shapes) + j, sh) for layer in range(n_layers) for j, sh in enumerate(shapes)]
     model_elems = sum(o * i for _, (o, i) in model)
+    placement = args.placement
+    if placement == "auto":
+        placement = "expert" if geometry.startswith("mixtral") else "lpt"
     if args.scaling == "strong" and world > 1:
-        from nncf_amd.distributed import partition_lpt
-
-        mine = sorted(partition_lpt([o * i for _, (o, i) in model], world)[rank])
+        mine = shard_of(model, len(shapes), world, placement)[rank]
         job = Job([model[k] for k in mine], mode, gs, device, seed=0)
     else:
-        job = Job(model, mode, gs, device, seed=rank)
+        order = sorted(range(len(model)), key=lambda k: (-model[k][1][0] * model[k][1][1], k))
+        job = Job([model[k] for k in order], mode, gs, device, seed=rank)
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ranks_seen = 1
+    if dist is not None:  # how many ranks the collective backend really connects (the driver checks it against N)
+        one = torch.ones(1, device=coll_dev, dtype=torch.int64)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     for _ in range(args.warmup):
         job.step()
@@ -210,11 +308,7 @@ def main():
     for _ in range(args.steps):
         job.step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     # kernel-side timing with HIP events on the launch stream (roofline leg)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -227,20 +321,50 @@ def main():
     torch.cuda.synchronize()
     dev_ms_per_step = ev0.elapsed_time(ev1) / ev_steps
 
-    gather_ms = None
-    if args.gather and dist is not None and not rehearsal:
+    # the exchange step of the path: every rank ends with the whole compressed model (packed codes + scales + zero
+    # points of all tensors).  ONE all_gather_into_tensor of the padded flat payload, RCCL over xGMI; always timed
+    # for N > 1 (the metric's end point is "gathered if multi-GPU", 8e: "with and without the gather").
+    gather_ms, gather_bytes = None, None
+    if dist is not None:
         payload = torch.cat([t.view(torch.uint8) for t in job.outs] + [t.view(torch.uint8) for t in job.scales]
-                            + [t.view(torch.uint8) for t in job.zps if t is not None])
-        size = torch.tensor([payload.numel()], device=device, dtype=torch.int64)
+                            + [t.view(torch.uint8) for t in job.zps if t is not None]
+                            or [torch.empty(0, dtype=torch.uint8, device=device)])
+        size = torch.tensor([payload.numel()], device=coll_dev, dtype=torch.int64)
         dist.all_reduce(size, op=dist.ReduceOp.MAX)  # shards differ by a few tensors: pad to the longest
         pad = (int(size.item()) + 15) // 16 * 16
-        payload = torch.cat([payload, torch.zeros(pad - payload.numel(), dtype=torch.uint8, device=device)])
-        out = torch.empty(world * pad, dtype=torch.uint8, device=device)
+        send = torch.zeros(pad, dtype=torch.uint8, device=device)
+        send[:payload.numel()] = payload
+        del payload
+        if rehearsal:  # gloo: host buffers; exercises the code path, says nothing about xGMI
+            send = send.cpu()
+        out = torch.empty(world * pad, dtype=torch.uint8, device=send.device)
+        gather_bytes = world * pad
+        reps = 1 if rehearsal else 3
+        dist.all_gather_into_tensor(out, send)  # untimed first call: communicator / channel set-up
         barrier()
         t1 = time.perf_counter()
-        dist.all_gather_into_tensor(out, payload)
+        for _ in range(reps):
+            dist.all_gather_into_tensor(out, send)
         barrier()
-        gather_ms = (time.perf_counter() - t1) * 1e3
+        gather_ms = max_over_ranks((time.perf_counter() - t1) / reps) * 1e3
+        del out, send
+
+    # sustained leg: the same step back to back for >= sustained_s seconds (DVFS settled), wall clock + HIP events
+    sustained = None
+    if args.sustained_s > 0 and job.n:
+        n_sus = max(args.steps, int(args.sustained_s / max(dev_ms_per_step * 1e-3, 1e-6)) + 1)
+        n_sus = min(n_sus, 200000)
+        sev0, sev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        ts = time.perf_counter()
+        sev0.record(job.stream)
+        for _ in range(n_sus):
+            job.step()
+        sev1.record(job.stream)
+        barrier()
+        sus_wall = max_over_ranks(time.perf_counter() - ts)
+        sustained = {"steps": n_sus, "seconds": round(sus_wall, 3), "ms_per_step": sus_wall / n_sus * 1e3,
+                     "device_ms_per_step": sev0.elapsed_time(sev1) / n_sus}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -260,18 +384,20 @@ def main():
             launches = sum(-(-c // job._lib.MAX_BATCH) for c in per_class.values())
             kernel = "wc::k_rows_batch<IntPolicyT<%s>, bf16> (%d row-length classes)" % (mode.upper(), len(per_class))
         # HBM bytes per launch: NOT measured by this run.  The figure is read from the committed rocprofv3 --pmc passes
-        # of this same command (profiles/r2_traffic.json, made by tools/traffic_from_pmc.py) and labelled as such;
+        # of this same command (profiles/r*_traffic.json, made by tools/traffic_from_pmc.py) and labelled as such;
         # null for any other shape of run.
         traffic, traffic_source = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as fh:
-                entry = json.load(fh).get(args.workload, {})
+        for name in ("r3_traffic.json", "r2_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    entry = json.load(fh).get(args.workload, {})
+            except OSError:
+                continue
             if not args.layers and world == 1 and entry.get("traffic_bytes_per_launch") is not None:
                 traffic = entry["traffic_bytes_per_launch"]
-                traffic_source = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                traffic_source = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
                                  "committed; not re-measured by this run)"
-        except OSError:
-            pass
+                break
         res = {
             "metric": "GB/s bf16 weights compressed (node)",
             "value": round(value, 2),
@@ -289,8 +415,10 @@ def main():
                                    f"bf16 random-init, {mode} group_size={gs}, fused quantize+pack, data-free RTN",
                        "tensors_in_model": len(model), "elements_in_model": model_elems,
                        "tensors_on_rank0": job.n, "elements_on_rank0": job.elems,
-                       "partition": ("ONE model: tensor list cut by LPT over the ranks, each rank holds and compresses "
-                                     "only its shard; no data-path collective") if strong else
+                       "partition": (("ONE model: expert e -> rank e % N (the three matrices of an expert stay together), "
+                                      if placement == "expert" else "ONE model: tensor list cut by LPT over the ranks, ")
+                                     + "each rank holds and compresses only its shard, largest weight first; no "
+                                       "data-path collective inside the timed region") if strong else
                                     "each rank compresses its own whole model; no collective"},
             "model_wall_ms": round(ms_per_step, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -300,10 +428,26 @@ def main():
                          "algorithmic_bytes_per_launch": round(job.alg_bytes / max(launches, 1), 1),
                          "device_ms_per_step": round(dev_ms_per_step, 4)},
         }
+        if sustained is not None:
+            res["sustained_ms_per_step"] = round(sustained["ms_per_step"], 4)
+            res["sustained"] = {"steps": sustained["steps"], "seconds": sustained["seconds"],
+                                "device_ms_per_step": round(sustained["device_ms_per_step"], 4),
+                                "value": round(total_in_bytes / (sustained["ms_per_step"] * 1e-3) / 1e9, 2),
+                                "roofline_frac": round(job.alg_bytes / (sustained["device_ms_per_step"] * 1e-3) / 1e9
+                                                       / HBM_PEAK_GBS, 4)}
+        if world > 1:
+            res["ranks_seen"] = ranks_seen
+            res["launcher"] = "bench.py --gpus N (own rank processes)" if os.environ.get("NNCF_AMD_BENCH_SPAWNED") \
+                else "external (torchrun)"
+            res["collective_backend"] = "gloo (rehearsal)" if rehearsal else "nccl (RCCL)"
         if rehearsal:
             res["rehearsal"] = f"{world} ranks share {n_dev} GPU(s), gloo barrier: exercises the sharded code path, not a scaling number"
         if gather_ms is not None:
             res["allgather_ms"] = round(gather_ms, 3)
+            res["allgather_bytes_per_rank_out"] = gather_bytes
+            # the 8(d) metric with its multi-GPU end point: compressed model resident on EVERY rank
+            res["value_gathered"] = round(total_in_bytes / ((ms_per_step + gather_ms) * 1e-3) / 1e9, 2)
+            res["model_wall_ms_gathered"] = round(ms_per_step + gather_ms, 4)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(geometry, mode, gs)
         else:

@@ -24,14 +24,46 @@ def partition_lpt(sizes: Sequence[int], world_size: int) -> List[List[int]]:
     return parts
 
 
+def partition_by_expert(expert_of: Sequence[int], world_size: int) -> List[List[int]]:
+    """BASELINE configs[4] ("C5 uses expert index -> rank"): item i belongs to expert expert_of[i] and goes
+    to rank expert % world_size, so the w1 / w2 / w3 of one expert (and the same expert of every layer) stay on one
+    rank -- the placement an expert-parallel model already has.  Within a rank the items keep their list order."""
+    parts: List[List[int]] = [[] for _ in range(world_size)]
+    for i, e in enumerate(expert_of):
+        parts[int(e) % world_size].append(i)
+    return parts
+
+
 def owner_of(parts: List[List[int]]) -> Dict[int, int]:
     return {i: r for r, p in enumerate(parts) for i in p}
 
 
+SLOT_ALIGN = 16  # every tensor of a flat payload starts on a 16-byte boundary (view(dtype) needs element alignment)
+
+
+def _slot(nbytes: int) -> int:
+    return (nbytes + SLOT_ALIGN - 1) // SLOT_ALIGN * SLOT_ALIGN
+
+
+def _spec_nbytes(shape, dtype) -> int:
+    numel = 1
+    for s in shape:
+        numel *= s
+    return numel * torch.empty(0, dtype=dtype).element_size()
+
+
 def _flatten(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Concatenation of the tensors' bytes, each padded to its 16-byte slot."""
     if not tensors:
         return torch.empty(0, dtype=torch.uint8)
-    return torch.cat([t.contiguous().view(torch.uint8).reshape(-1) for t in tensors])
+    pieces = []
+    for t in tensors:
+        b = t.contiguous().view(torch.uint8).reshape(-1) if t.numel() else torch.empty(0, dtype=torch.uint8, device=t.device)
+        pieces.append(b)
+        gap = _slot(b.numel()) - b.numel()
+        if gap:
+            pieces.append(torch.zeros(gap, dtype=torch.uint8, device=t.device))
+    return torch.cat(pieces)
 
 
 def all_gather_payloads(local: Sequence[torch.Tensor], specs: Sequence[Sequence[Tuple[Tuple[int, ...], torch.dtype]]],
@@ -43,17 +75,10 @@ def all_gather_payloads(local: Sequence[torch.Tensor], specs: Sequence[Sequence[
     rank = dist.get_rank(group)
 
     def nbytes(spec):
-        n = 0
-        for shape, dtype in spec:
-            numel = 1
-            for s in shape:
-                numel *= s
-            n += numel * torch.empty(0, dtype=dtype).element_size()
-        return n
+        return sum(_slot(_spec_nbytes(shape, dtype)) for shape, dtype in spec)
 
     sizes = [nbytes(s) for s in specs]
-    pad = max(sizes) if sizes else 0
-    pad = (pad + 15) // 16 * 16
+    pad = max(sizes) if sizes else 0  # a multiple of SLOT_ALIGN, so every rank's block starts aligned too
     dev = local[0].device if local else torch.device("cpu")
     send = torch.zeros(pad, dtype=torch.uint8, device=dev)
     flat = _flatten(local).to(dev)
@@ -67,23 +92,28 @@ def all_gather_payloads(local: Sequence[torch.Tensor], specs: Sequence[Sequence[
         off = r * pad
         items = []
         for shape, dtype in specs[r]:
-            numel = 1
-            for s in shape:
-                numel *= s
-            nb = numel * torch.empty(0, dtype=dtype).element_size()
+            nb = _spec_nbytes(shape, dtype)
             items.append(recv[off:off + nb].view(dtype).reshape(shape))
-            off += nb
+            off += _slot(nb)
         out.append(items)
     return out
 
 
-def compress_sharded(weights: Sequence[torch.Tensor], config, compress_fn, gather: bool = True, group=None):
+def compress_sharded(weights: Sequence[torch.Tensor], config, compress_fn, gather: bool = True, group=None,
+                     expert_of: Sequence[int] = None):
     """weights: the same ordered list (shapes at least) on every rank; each rank compresses only the tensors it owns
     with compress_fn(list_of_tensors, config) -> list of CompressedWeight-like objects (tensor, scale, zero_point).
+    Placement: LPT on the element count, or -- when expert_of[i] names the expert of weight i (MoE expert weights,
+    BASELINE configs[4]) -- expert e on rank e % world.
     Returns {index: (tensor, scale, zero_point)} for the owned tensors, or for ALL tensors when gather=True."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    parts = partition_lpt([w.numel() for w in weights], world)
+    if expert_of is not None:
+        if len(expert_of) != len(weights):
+            raise ValueError("compress_sharded: expert_of must name one expert per weight")
+        parts = partition_by_expert(expert_of, world)
+    else:
+        parts = partition_lpt([w.numel() for w in weights], world)
     mine = parts[rank]
     results = compress_fn([weights[i] for i in mine], config) if mine else []
     local = {i: (cw.tensor, cw.scale, cw.zero_point) for i, cw in zip(mine, results)}

@@ -31,6 +31,21 @@ def test_partition_lpt_is_balanced_and_deterministic():
     assert partition_lpt([5], 3) == [[0], [], []]
 
 
+def test_partition_by_expert_keeps_an_expert_on_one_rank():
+    """configs[4] places expert e on rank e % N, so w1 / w2 / w3 of an expert (every layer) share a rank."""
+    from nncf_amd.distributed import partition_by_expert
+    n_layers, n_experts = 4, 8
+    expert_of = [e for _ in range(n_layers) for e in range(n_experts) for _ in range(3)]
+    for world in (1, 2, 4, 8):
+        parts = partition_by_expert(expert_of, world)
+        assert sorted(i for p in parts for i in p) == list(range(len(expert_of)))
+        for r, p in enumerate(parts):
+            assert {expert_of[i] % world for i in p} <= {r}
+            assert len(p) == len(expert_of) // world
+    assert partition_by_expert([], 2) == [[], []]
+    assert partition_by_expert([5, 5, 6], 4) == [[], [0, 1], [2], []]
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -62,6 +77,23 @@ def _worker(rank, world, port, q):
                 and np.array_equal(zp.numpy(), z)
         local_only = compress_sharded(weights, "int4_asym", fake_compress, gather=False)
         ok = ok and 0 < len(local_only) < len(shapes)
+        # expert placement: weight i of expert i // 2 -> rank (i // 2) % world, same gathered result
+        by_expert = compress_sharded(weights, "int4_asym", fake_compress, gather=False, expert_of=[0, 0, 1, 1, 2])
+        ok = ok and sorted(by_expert) == ([0, 1, 4] if rank == 0 else [2, 3])
+        res_e = compress_sharded(weights, "int4_asym", fake_compress, gather=True, expert_of=[0, 0, 1, 1, 2])
+        ok = ok and all(torch.equal(res_e[i][0], res[i][0]) and torch.equal(res_e[i][1], res[i][1]) for i in res)
+        # payloads whose byte counts are not multiples of 4 (packed int4 of 3 x 6 values = 9 bytes, odd int8 rows)
+        # in front of fp32 / int32 tensors: every tensor has its own 16-byte slot in the flat buffer
+        from nncf_amd.distributed import all_gather_payloads
+
+        mine_odd = [torch.arange(9 + rank, dtype=torch.uint8), torch.full((3,), 1.5 + rank), torch.arange(5, dtype=torch.int8),
+                    torch.arange(3, dtype=torch.int32) + rank]
+        specs = [[((9 + r,), torch.uint8), ((3,), torch.float32), ((5,), torch.int8), ((3,), torch.int32)] for r in range(world)]
+        got = all_gather_payloads(mine_odd, specs)
+        for r in range(world):
+            ok = ok and torch.equal(got[r][0], torch.arange(9 + r, dtype=torch.uint8)) \
+                and torch.equal(got[r][1], torch.full((3,), 1.5 + r)) and torch.equal(got[r][2], torch.arange(5, dtype=torch.int8)) \
+                and torch.equal(got[r][3], torch.arange(3, dtype=torch.int32) + r)
         # data-parallel statistics: 5 samples over 2 ranks (ragged), bf16 means keep their bits and their order
         from nncf_amd.distributed import all_gather_sample_statistics, shard_samples
 

@@ -59,3 +59,25 @@ def test_nccl_backend_paths(nccl_world):
     got = D.gptq_sharded(units, WeightCompressionConfig("int4_sym", 64), lambda i: (xs, wts))
     assert sorted(got) == ["a", "b"] and got["a"][2] is None
     assert tuple(got["a"][1].shape) == (48, 4, 1) and got["a"][0].numel() == 48 * 256 // 2
+
+
+@pytest.mark.timeout(400)
+def test_bench_gpus_2_from_plain_python():
+    """The driver's command `python bench.py --gpus 2 ...` (no launcher): two rank processes of bench.py's own,
+    n_gpus 2, both ranks seen by the collective, the gathered metric present.  On a one-GPU box the ranks share the
+    card (marked `rehearsal`, gloo); on a multi-GPU box the same command runs RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "tiny-int4sym-g128",
+                        "--steps", "3", "--warmup", "1", "--sustained-s", "0.05"], env=env, capture_output=True,
+                       text=True, timeout=360)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["value"] > 0 and line["value_gathered"] > 0 and line["allgather_ms"] > 0
+    assert line["config"]["tensors_on_rank0"] == 3 and line["sustained_ms_per_step"] > 0
+    if torch.cuda.device_count() < 2:
+        assert "rehearsal" in line
