@@ -230,17 +230,6 @@ int nncf_amd_hessian_accumulate_list(float* h, int n, const void* const* xs_host
                                      int x_dtype, int64_t k, float alpha, void* stream);
 
 /*
- * Fused inner step of scale estimation (ScaleEstimation.calculate_quantization_params,
- * src/nncf/quantization/algorithms/weight_compression/scale_estimation.py:300-360; get_target_zero_mask :380-393,
- * estimate_scales :396-409): quantize every group with the candidate `scale` (and `zero_point`, fp32 as scale
- * estimation carries it; NULL for symmetric / float modes), target = q - zp, zero_mask = zero_scale * isclose(target, 0),
- *     out[g] = sum_k |w[g,k]| / (|target[g,k]| + zero_mask[g,k]) * importance[g,k]
- * weight, importance: fp32 [n_groups, group_size] (the grouped view, contiguous); scale, zero_point, out: fp32 [n_groups].
- */
-int nncf_amd_se_estimate(const float* weight, const float* importance, int64_t n_groups, int64_t group_size, int mode,
-                         const float* scale, const float* zero_point, float zero_scale, float* out, void* stream);
-
-/*
  * One whole search step of scale estimation for a weight (scale_estimation.py:268-360), fused: candidate scale ->
  * quantize -> ideal-scale estimate (`near`) -> quantize-dequantize with `near` -> output error of every group against
  * fp_outs (the [group_size x n_samples] activation slice sits in LDS, the contraction runs on the fp32 MFMA) -> the
@@ -257,8 +246,10 @@ int nncf_amd_se_estimate(const float* weight, const float* importance, int64_t n
  *   kind 0: near = scale0, best_diffs = diff, result_scale = scale0 (the min-max baseline, :252-262), fp_outs written;
  *   kind 1: candidate = result_scale (rectification step, :268-298); kind 2: candidate = factor * scale0 (grid step,
  *   :300-360); both update best_diffs / result_scale in place.  weight_penalty <= 0 disables the penalty term.
- * group_size in {32, 64, 128}, 1 <= n_samples <= 64 (nncf_amd_se_step_supported); other shapes take the unfused path
- * of the host mirror.
+ * Every group size >= 1 (whole-row groups included) and every n_samples >= 1 is served: group_size in {32, 64, 128}
+ * with n_samples <= 64 (nncf_amd_se_step_supported == 1: the reference's defaults) by the tiled MFMA kernel, which
+ * reads zero_mask / rden; everything else by a kernel that rebuilds the importance itself (zero_mask / rden may be
+ * NULL then, nncf_amd_se_zero_mask returns without a launch for such shapes).
  */
 int nncf_amd_se_step_supported(int64_t group_size, int64_t n_samples);
 int nncf_amd_se_zero_mask(const void* weight, int w_dtype, const float* s_per_channel, const float* scale0,
@@ -278,11 +269,13 @@ int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t* zero_mask,
  * in ONE launch; the host sums the tiles (fixed order) and divides by rows * n_samples to get cur_diff (:345).
  *   weight: fp32, rows of pitch row_pitch; group_offsets (DEVICE int64 [groups]): element offset of the group's first
  *   column in row 0 (+ the expert offset for 3-D weights);  scales: fp32 [groups, steps, group_size] (cur_scale, after
- *   the clamp of :315-335);  sacts: fp32 [groups, steps, group_size, 16, NT] = gacts[k][t*16 + c] / scale[k] (:342) with
- *   NT = 1 / 2 / 4 sample tiles for n_samples <= 16 / 32 / 64, zero beyond the samples;  fp_out: fp32
- *   [groups, rows, n_samples] (:307);  partial: fp32 [groups, steps, ceil(rows / 16)].
- * group_size in {32, 64, 128}, n_samples <= 64 (nncf_amd_se_step_supported).
+ *   the clamp of :315-335);  sacts = gacts[k][j] / scale[k] (:342), fp32, in the layout nncf_amd_awq_sacts_tiles names
+ *   for the shape: NT = 1 / 2 / 4 (group_size in {32, 64, 128}, n_samples <= 16 / 32 / 64: the tiled MFMA kernel) ->
+ *   [groups, steps, group_size, 16, NT] holding sample t*16 + c at [.., c, t], zero beyond the samples, 16-byte
+ *   aligned; 0 (every other group size >= 1 / sample count) -> plain [groups, steps, group_size, n_samples];
+ *   fp_out: fp32 [groups, rows, n_samples] (:307);  partial: fp32 [groups, steps, ceil(rows / 16)].
  */
+int nncf_amd_awq_sacts_tiles(int64_t group_size, int64_t n_samples);
 int nncf_amd_awq_search(const float* weight, int64_t rows, int64_t row_pitch, const int64_t* group_offsets, int groups,
                         int64_t group_size, const float* scales, int steps, const float* sacts, const float* fp_out,
                         int64_t n_samples, int mode, float* partial, void* stream);

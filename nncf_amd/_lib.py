@@ -51,14 +51,13 @@ SIGNATURES = {
     "nncf_amd_reduce_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "nncf_amd_reduce_activation_stats": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                                  c_void_p, c_size_t, c_void_p]),
-    "nncf_amd_se_estimate": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p,
-                                     c_void_p]),
     "nncf_amd_se_step_supported": (c_int, [c_int64, c_int64]),
     "nncf_amd_se_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_float,
                                  c_float, c_float, c_void_p]),
     "nncf_amd_se_zero_mask": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                       c_int, c_void_p, c_void_p, c_void_p]),
+    "nncf_amd_awq_sacts_tiles": (c_int, [c_int64, c_int64]),
     "nncf_amd_awq_search": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p,
                                     c_int64, c_int, c_void_p, c_void_p]),
     "nncf_amd_decompress": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -1,10 +1,9 @@
-"""Host-side mirror of the AWQ tensor math (src/nncf/quantization/algorithms/weight_compression/awq.py:243-366)
-for torch tensors on an AMD GPU: the alpha grid search per outlier group (fake-quantize through the fused HIP
-quantize-dequantize kernel + small matmuls) and the data-free scale.  Graph pattern matching and the insertion of
-the activation multiply stay with the caller (the reference's own Python)."""
+"""AWQ tensor math (src/nncf/quantization/algorithms/weight_compression/awq.py:243-366) for torch tensors on an AMD
+GPU: the alpha grid search of every outlier group in one fused launch (nncf_amd_awq_search, csrc/wc_se.hip: scale,
+per-row parameters, quantize-dequantize, contraction with the scaled activations, sum of |diff|) for any group size,
+and the data-free scale.  Graph pattern matching and the insertion of the activation multiply stay with the caller."""
 from __future__ import annotations
 
-from copy import deepcopy
 from typing import Optional
 
 import numpy as np
@@ -13,11 +12,9 @@ import torch
 from nncf_amd import _lib
 from nncf_amd.parameters import WeightCompressionConfig, as_config
 from nncf_amd.statistics import WCTensorStatistic, process_stats
-from nncf_amd.weight_lowering import float_quantize_dequantize_weight, integer_quantize_dequantize_weight
 
 FP16_MAX_VALUE = 65504.0
 FP16_OVERFLOW_MARGIN = 0.25
-FUSED_SEARCH = True  # developer switch: False takes the per-group torch path for every shape
 GROUPS_PER_LAUNCH = 64
 
 
@@ -60,7 +57,7 @@ def _candidate_scales(gscale, alpha_min, alpha_step, steps, gprev, prev_s, n_pre
     return all_scales
 
 
-def _fused_group_search(weight, s, X, config, group_size, groups, scale, alpha_min, alpha_step, steps, prev_s, prev_w, n_prev):
+def _group_search(weight, s, X, config, group_size, groups, scale, alpha_min, alpha_step, steps, prev_s, prev_w, n_prev):
     """All outlier groups and all alpha steps through nncf_amd_awq_search (one launch per GROUPS_PER_LAUNCH groups):
     the weight slice of a group is read once and stays in registers for its alpha steps; the per-group preparation
     of the reference's loop body (awq.py:298-308) runs batched over the groups.  weight: fp32 contiguous [B, N, K];
@@ -68,10 +65,10 @@ def _fused_group_search(weight, s, X, config, group_size, groups, scale, alpha_m
     B, N, K = weight.shape
     G = K // group_size
     n = X.shape[-1]
-    nt = 1 if n <= 16 else (2 if n <= 32 else 4)
+    lib = _lib.lib()
+    nt = int(lib.nncf_amd_awq_sacts_tiles(group_size, n))  # 1 / 2 / 4: the tiled kernel's layout; 0: plain
     dev = weight.device
     tiles = (N + 15) // 16
-    lib = _lib.lib()
     mode_id = _lib.MODE_ID[config.mode.value]
     w4 = weight.view(B, N, G, group_size)
     for c0 in range(0, len(groups), GROUPS_PER_LAUNCH):
@@ -89,9 +86,11 @@ def _fused_group_search(weight, s, X, config, group_size, groups, scale, alpha_m
         gprev = prev_w.reshape(B, G, group_size)[bi, gi] if prev_s is not None else None
         all_scales = _candidate_scales(gscale, alpha_min, alpha_step, steps, gprev, prev_s, n_prev).contiguous()
         sacts = gacts.unsqueeze(1) / all_scales.unsqueeze(3)            # [nc, steps, gs, n]  (awq.py:342)
-        if n < 16 * nt:
-            sacts = torch.nn.functional.pad(sacts, (0, 16 * nt - n))
-        sacts = sacts.reshape(nc, steps, group_size, nt, 16).transpose(3, 4).contiguous()  # kernel layout [.., 16, NT]
+        if nt:
+            if n < 16 * nt:
+                sacts = torch.nn.functional.pad(sacts, (0, 16 * nt - n))
+            sacts = sacts.reshape(nc, steps, group_size, nt, 16).transpose(3, 4)  # kernel layout [.., 16, NT]
+        sacts = sacts.contiguous()
         goff = bi * (N * K) + gi * group_size
         partial = torch.empty((nc, steps, tiles), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -118,74 +117,37 @@ def data_aware_step(weight: torch.Tensor, reduction_axes, config: WeightCompress
                     statistics: WCTensorStatistic, act_ch_axis: int = -1, subset_size: int = 32,
                     percent_to_apply: float = 0.002, alpha_min: float = 0.0, alpha_max: float = 1.0, steps: int = 100,
                     prev_weight: Optional[torch.Tensor] = None, prev_statistics: Optional[WCTensorStatistic] = None):
-    """awq.py:243-357 -> per-input-channel scale [hidden] (or [experts, hidden])."""
+    """awq.py:243-357 -> per-input-channel scale [hidden] (or [experts, hidden]): 1 everywhere except in the groups
+    that hold the largest activation channels, where the alpha search of `_group_search` decides."""
     config = as_config(config)
-    alpha_step = (alpha_max - alpha_min) / steps
-    s, X = process_stats(statistics, subset_size, act_ch_axis)
-    s = s.to(torch.float32)
-    X = X.to(torch.float32)
-    weight = weight.to(torch.float32)
-    is_2d_weight = weight.ndim == 2
-    reduction_axis = reduction_axes[0]
-    if is_2d_weight:
-        s, X, weight = s.unsqueeze(0), X.unsqueeze(0), weight.unsqueeze(0)
-        prev_weight = prev_weight.unsqueeze(0) if prev_weight is not None else None
-        reduction_axis += 1
-    prev_s, prev_w = None, None
+    _lib.require_gpu(weight, "AWQ data-aware step")
+    magnitude, samples = process_stats(statistics, subset_size, act_ch_axis)
+    experts = weight.ndim == 3
+    red = reduction_axes[0] % weight.ndim
+    w3 = weight.to(torch.float32)
+    if red != weight.ndim - 1:  # hidden axis last: [.., out, hidden]
+        w3 = torch.movedim(w3, -1, -2)
+    if not experts:
+        w3, magnitude, samples = w3.unsqueeze(0), magnitude.unsqueeze(0), samples.unsqueeze(0)
+    magnitude, samples = magnitude.to(torch.float32), samples.to(torch.float32)
+    hidden = magnitude.shape[-1]
+    gs = hidden if config.group_size == -1 else config.group_size
+    # the groups of the top 0.2 % channels (at least one; earliest channel first among equals, :279-291)
+    n_top = max(int(hidden * percent_to_apply), 1)
+    order = torch.sort(-magnitude, dim=-1, stable=True)[1][:, :n_top]
+    groups = sorted({(b, c // gs) for b, row in enumerate(order.tolist()) for c in row})
+    # merged with the previous matmul: its mean |weight| per channel and the largest activation magnitude in front of
+    # it drive the fp16-overflow clamp of the candidates (:263-275, 315-335)
+    prev_peak, prev_mean, prev_len = None, None, 0
     if prev_statistics is not None and prev_weight is not None:
-        prev_s, _ = process_stats(prev_statistics, subset_size, act_ch_axis)
-        prev_s = prev_s.to(torch.float32).max().item()
-        prev_w = torch.mean(torch.abs(prev_weight.to(torch.float32)), dim=reduction_axis)
-    top_k = max(int(s.shape[-1] * percent_to_apply), 1)
-    topk_idxs = torch.sort(-s, dim=-1, stable=True)[1][:, :top_k].cpu()
-    group_size = config.group_size if config.group_size != -1 else s.shape[-1]
-    groups_to_correct = set()
-    for batch_idx in range(topk_idxs.shape[0]):
-        for k_idx in range(topk_idxs.shape[1]):
-            groups_to_correct.add((batch_idx, int(topk_idxs[batch_idx, k_idx]) // group_size))
-    groups_to_correct = sorted(groups_to_correct)
-    if reduction_axis == 1:
-        weight = torch.movedim(weight, -1, -2)
-    scale = torch.ones_like(torch.mean(X, dim=-1))
-    awq_config = deepcopy(config)
-    awq_config.group_size = -1
-    qdq = integer_quantize_dequantize_weight if config.is_integer else float_quantize_dequantize_weight
-    if (FUSED_SEARCH and weight.is_cuda and groups_to_correct
-            and bool(_lib.lib().nncf_amd_se_step_supported(group_size, X.shape[-1]))):
-        _fused_group_search(weight.contiguous(), s, X, config, group_size, groups_to_correct, scale, alpha_min, alpha_step,
-                            steps, prev_s, prev_w, prev_weight.shape[reduction_axis] if prev_weight is not None else 0)
-        return scale.squeeze(0) if is_2d_weight else scale
-    for batch_idx, gi in groups_to_correct:
-        offset = gi * group_size
-        gscale = s[batch_idx, offset:offset + group_size]
-        gweight = weight[batch_idx, :, offset:offset + group_size]
-        gacts = X[batch_idx, offset:offset + group_size, :]
-        a_min = torch.quantile(gscale, 0.1).to(torch.float32)
-        gscale = torch.clip(gscale, min=a_min, max=1e2)
-        fp32_out = torch.matmul(gweight, gacts)
-        # The reference walks the 100 alphas one by one (awq.py:300-348: ~10 small ops per step).  Here all steps of
-        # a group go through the same arithmetic at once: [steps, N, gs] scaled weights -> ONE quantize-dequantize
-        # launch (rows are independent) -> batched matmul -> per-step mean |diff|; the running "strictly better"
-        # minimum of the reference is the argmin with the earliest index on ties.
-        min_diff = torch.max(torch.abs(fp32_out))
-        gprev = prev_w[batch_idx, offset:offset + group_size] if prev_s is not None else None
-        all_scales = _candidate_scales(gscale, alpha_min, alpha_step, steps, gprev, prev_s,
-                                       prev_weight.shape[reduction_axis] if prev_weight is not None else 0)
-        n_rows, n_tok = gweight.shape[0], gacts.shape[1]
-        chunk = max(1, min(steps, (1 << 28) // max(1, n_rows * max(group_size, n_tok))))  # <= 1 GiB of fp32 per temporary
-        diffs = []
-        for c0 in range(0, steps, chunk):
-            sc = all_scales[c0:c0 + chunk]
-            scaled = (gweight.unsqueeze(0) * sc.unsqueeze(1)).reshape(-1, gweight.shape[1]).contiguous()
-            g_dq = qdq(scaled, awq_config, -1).reshape(sc.shape[0], n_rows, -1)
-            sacts = gacts.unsqueeze(0) / sc.unsqueeze(2)
-            cur_out = torch.bmm(g_dq, sacts)
-            diffs.append(torch.mean(torch.abs(cur_out - fp32_out.unsqueeze(0)), dim=(1, 2)))
-        diffs = torch.cat(diffs)
-        best = int(torch.argmin(diffs))
-        best_scale = all_scales[best] if bool(diffs[best] < min_diff) else None
-        if best_scale is not None:
-            scale[batch_idx, offset:offset + group_size] = best_scale
-    if is_2d_weight:
-        scale = scale.squeeze(0)
-    return scale
+        pw = prev_weight.to(torch.float32)
+        pred = red if experts else red + 1
+        pw = pw if experts else pw.unsqueeze(0)
+        prev_peak = process_stats(prev_statistics, subset_size, act_ch_axis)[0].to(torch.float32).max().item()
+        prev_mean = pw.abs().mean(dim=pred)
+        prev_len = pw.shape[pred]
+    scale = torch.ones(magnitude.shape, dtype=torch.float32, device=weight.device)
+    if groups:
+        _group_search(w3.contiguous(), magnitude, samples, config, gs, groups, scale, alpha_min,
+                      (alpha_max - alpha_min) / steps, steps, prev_peak, prev_mean, prev_len)
+    return scale if experts else scale.squeeze(0)

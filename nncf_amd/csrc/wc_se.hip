@@ -1,93 +1,11 @@
-// wc_se.hip -- fused inner step of scale estimation (scale_estimation.py:300-360 with :380-409): for a candidate
-// scale per group, quantize the group, form target = q - zp and zero_mask = 0.001 * isclose(target, 0), and return
-//     sum_k |w_k| / (|target_k| + zero_mask_k) * importance_k        (estimate_scales, :396-409)
-// in ONE pass over the weight and the importance (8 B per element) instead of ~10 elementwise torch kernels plus a
-// reduction (~80 B per element).  Quantization is the exact policy arithmetic of the lowering kernels.
+// wc_se.hip -- scale estimation (scale_estimation.py:160-409) and the AWQ alpha search (awq.py:297-352) as fused
+// kernels: ONE launch per candidate scale / per set of outlier groups instead of ~10 elementwise torch kernels, a
+// quantize-dequantize pass that writes the weight-sized tensor and a batched matmul that reads it back.  Two kernel
+// families behind each entry point: the tiled MFMA kernels (group sizes 32 / 64 / 128, <= 64 samples: the shapes of
+// the reference's defaults) and the `_any` kernels (every other group size incl. whole rows, any sample count).
+// Quantization is the exact policy arithmetic of the lowering kernels.
 #include "wc_float_policy.h"
 #include "wc_int_policy.h"
-
-namespace wc {
-
-template <typename Policy>
-__global__ __launch_bounds__(256) void k_se_estimate(const float* __restrict__ w, const float* __restrict__ imp, GroupArgs a,
-                                                     int64_t gs, float zero_scale, float* __restrict__ out) {
-    __shared__ float lds[kPolicyLds];
-    Policy::init_shared(lds);
-    __syncthreads();
-    const Policy pol(a, lds);
-    const int l = threadIdx.x & 15;
-    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-    const bool live = g < a.n_groups;
-    const int64_t gg = live ? g : a.n_groups - 1;  // idle lanes shadow the last group (they take part in the reduction)
-    const typename Policy::Par par = pol.load(a, gg);
-    const float* wg = w + gg * gs;
-    const float* ig = imp + gg * gs;
-    float acc = 0.0f;
-    auto term = [&](float wv, float iv) {
-        int code;
-        float val;
-        pol.quant(wv, par, code, val);
-        const float target = pol.target(val, par);
-        const float zm = fabsf(target) <= 1e-8f ? zero_scale : 0.0f;  // isclose(target, 0): atol 1e-8
-        acc += fabsf(wv) / (fabsf(target) + zm) * iv;
-    };
-    if ((gs & 3) == 0 && ((((uintptr_t)w | (uintptr_t)imp) & 15u) == 0)) {
-        for (int64_t k = l * 4; k < gs; k += 64) {
-            const float4 wv = *(const float4*)(wg + k);
-            const float4 iv = *(const float4*)(ig + k);
-            term(wv.x, iv.x);
-            term(wv.y, iv.y);
-            term(wv.z, iv.z);
-            term(wv.w, iv.w);
-        }
-    } else {
-        for (int64_t k = l; k < gs; k += 16) term(wg[k], ig[k]);
-    }
-    acc = lanes_allreduce<16>(acc, OpAdd());
-    if (live && l == 0) out[g] = acc;
-}
-
-}  // namespace wc
-
-extern "C" int nncf_amd_se_estimate(const float* weight, const float* importance, int64_t n_groups, int64_t group_size,
-                                    int mode, const float* scale, const float* zero_point, float zero_scale, float* out,
-                                    void* stream) {
-    using namespace wc;
-    if (n_groups < 0 || group_size < 1 || (n_groups > 0 && (!weight || !importance || !scale || !out))) {
-        set_error("se_estimate: bad argument (n_groups=%lld group_size=%lld)", (long long)n_groups, (long long)group_size);
-        return NNCF_AMD_ERR_BAD_ARG;
-    }
-    if (n_groups == 0) return NNCF_AMD_OK;
-    GroupArgs a = {};
-    a.scale_in = scale;
-    a.zp_in = zero_point;
-    a.zp_dtype = NNCF_AMD_ZP_F32;
-    a.n_groups = n_groups;
-    a.gs = group_size;
-    a.inner = 1;
-    a.mode = mode;
-    const dim3 grid((unsigned)((n_groups * 16 + 255) / 256));
-    hipStream_t s = (hipStream_t)stream;
-    if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
-        const bool asym = mode == NNCF_AMD_INT8_ASYM || mode == NNCF_AMD_INT4_ASYM;
-        if (asym && !zero_point) {
-            set_error("se_estimate: asymmetric mode needs the zero points");
-            return NNCF_AMD_ERR_BAD_ARG;
-        }
-        if (!asym) a.zp_in = nullptr;
-        hipLaunchKernelGGL((k_se_estimate<IntPolicy>), grid, dim3(256), 0, s, weight, importance, a, group_size, zero_scale, out);
-    } else if (mode == NNCF_AMD_NF4) {
-        a.zp_in = nullptr;
-        hipLaunchKernelGGL((k_se_estimate<FloatPolicy<true>>), grid, dim3(256), 0, s, weight, importance, a, group_size, zero_scale, out);
-    } else if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) {
-        a.zp_in = nullptr;
-        hipLaunchKernelGGL((k_se_estimate<FloatPolicy<false>>), grid, dim3(256), 0, s, weight, importance, a, group_size, zero_scale, out);
-    } else {
-        set_error("se_estimate: unsupported mode %d", mode);
-        return NNCF_AMD_ERR_MODE;
-    }
-    return launch_status("se_estimate");
-}
 
 // ====================================================================================================================
 // Fused search step of scale estimation (scale_estimation.py:268-360), one launch per candidate:
@@ -126,6 +44,7 @@ struct SeStepArgs {
     int64_t rows, groups;
     int ns, mode, kind;
     float factor, zero_scale, weight_penalty;
+    int64_t batch;
 };
 
 template <int M>
@@ -386,6 +305,164 @@ __global__ __launch_bounds__(kSeThreads) void k_se_step(SeStepArgs a) {
     }
 }
 
+// Any group size / any number of samples (the tiled kernel above takes 32 / 64 / 128 x <= 64): a wave owns R = 4 rows
+// of one group.  Pass 1, lanes stride over the group's elements: zero mask of the min-max quantization and the sum of
+// the unmasked s (the importance of scale_estimation.py:236-247, rebuilt per step: no weight-sized mask is kept),
+// candidate quantization, ideal-scale sum -> `near`.  Pass 2, 64 elements at a time: every lane dequantizes one
+// element per row with `near`, then the 64 values are broadcast one after the other (v_readlane) against the lane's
+// sample column(s) of X[g] (coalesced 256-byte reads, L1 / L2 resident: the group's slice is shared by all rows).
+// More than 64 * NT samples: further passes over the group.  Same blends as the tiled kernel.
+template <typename Policy, int DT, int NT>
+__global__ __launch_bounds__(256) void k_se_step_any(SeStepArgs a, int64_t gs) {
+    constexpr int R = 4;
+    __shared__ float lut[kPolicyLds];
+    Policy::init_shared(lut);
+    __syncthreads();
+    GroupArgs ga = {};
+    ga.mode = a.mode;
+    const Policy pol(ga, lut);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t N = a.rows, G = a.groups;
+    const int ns = a.ns;
+    const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+    if (n0 >= N) return;  // (no block barrier below)
+    const bool has_zp = a.zp != nullptr;
+    const bool want_pen = a.weight_penalty > 0.0f;
+    for (int64_t e = blockIdx.z; e < a.batch; e += gridDim.z)
+        for (int64_t g = blockIdx.y; g < G; g += gridDim.y) {
+            const float* xg = a.x + ((e * G + g) * gs) * ns;
+            float* fo = a.fp_outs + ((e * G + g) * N) * ns;
+            int64_t pidx[R], wbase[R];
+            float sc0[R], zpf[R], near[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int64_t row = n0 + i < N ? n0 + i : N - 1;
+                pidx[i] = (e * N + row) * G + g;
+                wbase[i] = pidx[i] * gs;
+                sc0[i] = a.scale0[pidx[i]];
+                zpf[i] = has_zp ? a.zp[pidx[i]] : 0.0f;
+                near[i] = sc0[i];
+            }
+            if (a.kind != 0) {
+                const float* sg = a.s + (e * G + g) * gs;
+                typename Policy::Par p0[R], pc[R];
+                float den[R], acc[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    p0[i] = se_par(pol, sc0[i], zpf[i], has_zp);
+                    pc[i] = se_par(pol, a.kind == 1 ? a.result[pidx[i]] : a.factor * sc0[i], zpf[i], has_zp);
+                    den[i] = acc[i] = 0.0f;
+                }
+                for (int64_t k = lane; k < gs; k += 64) {
+                    const float sv = sg[k];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const float w = Elem<DT>::load(a.w, wbase[i] + k);
+                        int code;
+                        float v0, v;
+                        pol.quant(w, p0[i], code, v0);
+                        const float imp = fabsf(pol.target(v0, p0[i])) <= 1e-8f ? 0.0f : sv;  // isclose(target, 0): atol 1e-8
+                        den[i] += imp;
+                        pol.quant(w, pc[i], code, v);
+                        const float target = pol.target(v, pc[i]);
+                        const float zm = fabsf(target) <= 1e-8f ? a.zero_scale : 0.0f;
+                        acc[i] += fabsf(w) / (fabsf(target) + zm) * imp;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const float rd = 1.0f / (lanes_allreduce<64>(den[i], OpAdd()) + kEps);
+                    near[i] = (lanes_allreduce<64>(acc[i], OpAdd()) * rd) * (sc0[i] / fabsf(sc0[i]));
+                }
+            }
+            typename Policy::Par pn[R];
+            float sq[R], pen[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                pn[i] = se_par(pol, near[i], zpf[i], has_zp);
+                sq[i] = pen[i] = 0.0f;
+            }
+            for (int j0 = 0; j0 < ns; j0 += 64 * NT) {
+                float qa[R][NT], fa[R][NT];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) qa[i][t] = fa[i][t] = 0.0f;
+                for (int64_t k0 = 0; k0 < gs; k0 += 64) {
+                    const int64_t k = k0 + lane;
+                    float dqv[R], wv[R];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        wv[i] = dqv[i] = 0.0f;
+                        if (k < gs) {
+                            const float w = Elem<DT>::load(a.w, wbase[i] + k);
+                            int code;
+                            float v;
+                            pol.quant(w, pn[i], code, v);
+                            const float dq = pol.dq(0, v, pn[i]);
+                            if (want_pen && j0 == 0) pen[i] += (dq - w) * (dq - w);
+                            wv[i] = w;
+                            dqv[i] = dq;
+                        }
+                    }
+                    const int kn = gs - k0 < 64 ? (int)(gs - k0) : 64;
+                    const float* xr = xg + k0 * ns + j0 + lane;
+                    for (int kk = 0; kk < kn; ++kk) {
+                        float xv[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) xv[t] = (j0 + t * 64 + lane) < ns ? xr[(int64_t)kk * ns + t * 64] : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dqv[i]), kk));
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) qa[i][t] = fmaf(d, xv[t], qa[i][t]);
+                            if (a.kind == 0) {
+                                const float wl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv[i]), kk));
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) fa[i][t] = fmaf(wl, xv[t], fa[i][t]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int64_t row = n0 + i;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int col = j0 + t * 64 + lane;
+                        if (col < ns && row < N) {
+                            float f;
+                            if (a.kind == 0) {
+                                f = fa[i][t];
+                                fo[row * ns + col] = f;
+                            } else {
+                                f = fo[row * ns + col];
+                            }
+                            const float d = f - qa[i][t];
+                            sq[i] += d * d;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                float diff = lanes_allreduce<64>(sq[i], OpAdd()) / (float)ns;
+                if (want_pen) diff = diff + a.weight_penalty * (lanes_allreduce<64>(pen[i], OpAdd()) / (float)gs);
+                if (lane == 0 && n0 + i < N) {
+                    if (a.kind == 0) {
+                        a.best[pidx[i]] = diff;
+                        a.result[pidx[i]] = near[i];
+                    } else {
+                        const float b = a.best[pidx[i]], rs = a.result[pidx[i]];
+                        const float mask = diff > b ? 1.0f : 0.0f;
+                        a.best[pidx[i]] = mask * b + (1.0f - mask) * diff;
+                        a.result[pidx[i]] = mask * rs + (1.0f - mask) * near[i];
+                    }
+                }
+            }
+        }
+}
+
 // Zero mask + normaliser of the importance (scale_estimation.py:236-247): importance_k = (target0_k ~ 0 ? 0 : s_k) /
 // (sum + eps) with target0 the min-max quantization.  Instead of the importance (4 B per element, re-read by every
 // step) the steps get 1 bit per element (word q of a group = its q-th quarter) and 1 / (sum + eps) per group.
@@ -453,15 +530,33 @@ static int se_step_launch(const SeStepArgs& a, int64_t batch, hipStream_t s) {
     return launch_status("se_step");
 }
 
+// the `_any` kernel: R = 4 rows per wave, 4 waves per block; groups / batch entries beyond the grid limits are looped over
+template <typename Policy, int DT>
+static int se_step_any_launch(const SeStepArgs& a, int64_t gs, hipStream_t s) {
+    const dim3 grid((unsigned)((a.rows + 15) / 16), (unsigned)(a.groups < 65535 ? a.groups : 65535),
+                    (unsigned)(a.batch < 65535 ? a.batch : 65535));
+    if (a.ns <= 64)
+        hipLaunchKernelGGL((k_se_step_any<Policy, DT, 1>), grid, dim3(256), 0, s, a, gs);
+    else if (a.ns <= 128)
+        hipLaunchKernelGGL((k_se_step_any<Policy, DT, 2>), grid, dim3(256), 0, s, a, gs);
+    else
+        hipLaunchKernelGGL((k_se_step_any<Policy, DT, 4>), grid, dim3(256), 0, s, a, gs);
+    return launch_status("se_step (any group size)");
+}
+
+// shapes of the tiled MFMA kernels: the reference's default group sizes and sample subsets, vector-aligned rows
+static bool se_tiled_shape(int64_t gs, int64_t ns, int64_t groups, int64_t batch, const void* w) {
+    return (gs == 32 || gs == 64 || gs == 128) && ns >= 1 && ns <= 64 && groups <= 65535 && batch <= 65535 &&
+           ((uintptr_t)w & 15u) == 0;
+}
+
 template <typename Policy, int DT>
 static int se_step_gs(const SeStepArgs& a, int64_t batch, int64_t gs, hipStream_t s) {
+    if (!se_tiled_shape(gs, a.ns, a.groups, batch, a.w)) return se_step_any_launch<Policy, DT>(a, gs, s);
     switch (gs) {
         case 32: return se_step_launch<Policy, DT, 32>(a, batch, s);
         case 64: return se_step_launch<Policy, DT, 64>(a, batch, s);
-        case 128: return se_step_launch<Policy, DT, 128>(a, batch, s);
-        default:
-            set_error("se_step: group size %lld is not one of 32 / 64 / 128", (long long)gs);
-            return NNCF_AMD_ERR_UNSUPPORTED;
+        default: return se_step_launch<Policy, DT, 128>(a, batch, s);
     }
 }
 
@@ -475,6 +570,8 @@ static int se_step_dt(const SeStepArgs& a, int w_dtype, int64_t batch, int64_t g
 
 }  // namespace wc
 
+// 1: the shape runs on the tiled MFMA kernels (and nncf_amd_se_zero_mask fills zero_mask / rden for it); 0: on the
+// `_any` kernels, which rebuild the mask themselves.  Every shape is served; this is information, not a gate.
 extern "C" int nncf_amd_se_step_supported(int64_t group_size, int64_t n_samples) {
     return (group_size == 32 || group_size == 64 || group_size == 128) && n_samples >= 1 && n_samples <= 64;
 }
@@ -485,31 +582,20 @@ extern "C" int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t*
                                 int64_t rows, int64_t groups, int64_t group_size, int64_t n_samples, int mode, int kind,
                                 float factor, float zero_scale, float weight_penalty, void* stream) {
     using namespace wc;
-    if (batch < 0 || rows < 0 || groups < 0 || kind < 0 || kind > 2) {
+    if (batch < 0 || rows < 0 || groups < 0 || kind < 0 || kind > 2 || group_size < 1 || n_samples < 1 ||
+        n_samples > 0x7fffffff) {
         set_error("se_step: bad argument");
         return NNCF_AMD_ERR_BAD_ARG;
     }
     if (batch * rows * groups == 0) return NNCF_AMD_OK;
+    const bool tiled = se_tiled_shape(group_size, n_samples, groups, batch, weight);
     if (!weight || !x || !fp_outs || !scale0 || !best_diffs || !result_scale ||
-        (kind != 0 && (!zero_mask || !rden || !s_per_channel))) {
+        (kind != 0 && (!s_per_channel || (tiled && (!zero_mask || !rden))))) {
         set_error("se_step: NULL buffer");
         return NNCF_AMD_ERR_BAD_ARG;
     }
-    if (!nncf_amd_se_step_supported(group_size, n_samples)) {
-        set_error("se_step: group size %lld / %lld samples not supported (32, 64, 128 / 1..64)", (long long)group_size,
-                  (long long)n_samples);
-        return NNCF_AMD_ERR_UNSUPPORTED;
-    }
-    if (groups > 65535 || batch > 65535) {
-        set_error("se_step: more than 65535 groups per row or batch entries");
-        return NNCF_AMD_ERR_UNSUPPORTED;
-    }
-    if ((uintptr_t)weight & 15u) {
-        set_error("se_step: weight must be 16-byte aligned");
-        return NNCF_AMD_ERR_BAD_ARG;
-    }
     SeStepArgs a = {weight, zero_mask, rden, s_per_channel, x, fp_outs, scale0, zero_point, best_diffs, result_scale,
-                    rows, groups, (int)n_samples, mode, kind, factor, zero_scale, weight_penalty};
+                    rows, groups, (int)n_samples, mode, kind, factor, zero_scale, weight_penalty, batch};
     hipStream_t s = (hipStream_t)stream;
     if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
         const bool asym = mode == NNCF_AMD_INT8_ASYM || mode == NNCF_AMD_INT4_ASYM;
@@ -550,13 +636,18 @@ extern "C" int nncf_amd_se_zero_mask(const void* weight, int w_dtype, const floa
                                      const float* zero_point, int64_t batch, int64_t rows, int64_t groups,
                                      int64_t group_size, int mode, uint32_t* zero_mask, float* rden, void* stream) {
     using namespace wc;
-    if (batch < 0 || rows < 0 || groups < 0 || (group_size != 32 && group_size != 64 && group_size != 128) ||
-        ((uintptr_t)weight & 15u) || ((uintptr_t)s_per_channel & 15u)) {
-        set_error("se_zero_mask: bad argument (group size 32 / 64 / 128; weight and s_per_channel 16-byte aligned)");
+    if (batch < 0 || rows < 0 || groups < 0 || group_size < 1) {
+        set_error("se_zero_mask: bad argument");
         return NNCF_AMD_ERR_BAD_ARG;
     }
     const int64_t n_groups = batch * rows * groups;
     if (n_groups == 0) return NNCF_AMD_OK;
+    // shapes the `_any` step kernel serves need no mask: it rebuilds the importance itself (same rule as se_step's)
+    if (!se_tiled_shape(group_size, 1, groups, batch, weight)) return NNCF_AMD_OK;
+    if ((uintptr_t)s_per_channel & 15u) {
+        set_error("se_zero_mask: s_per_channel must be 16-byte aligned");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
     if (!weight || !s_per_channel || !scale0 || !zero_mask || !rden) {
         set_error("se_zero_mask: NULL buffer");
         return NNCF_AMD_ERR_BAD_ARG;
@@ -735,6 +826,117 @@ __global__ __launch_bounds__(256) void k_awq_search(AwqArgs a) {
     }
 }
 
+// Any group size / sample count: a wave owns a 16-row tile (four sets of R = 4 rows, so `partial` keeps the tiled
+// kernel's [groups, steps, ceil(rows / 16)] shape) of one group for a run of alpha steps.  Per step and row set: pass 1
+// strides the lanes over the group (scaled weight -> row statistics -> parameters), pass 2 dequantizes 64 elements at
+// a time and broadcasts them against the lane's sample column(s) of sacts[g, s] in the PLAIN layout
+// [groups, steps, group_size, n_samples].
+template <typename Policy, int NT>
+__global__ __launch_bounds__(256) void k_awq_search_any(AwqArgs a, int64_t gs) {
+    constexpr int R = 4;
+    __shared__ float lut[kPolicyLds];
+    Policy::init_shared(lut);
+    __syncthreads();
+    GroupArgs ga = {};
+    ga.mode = a.mode;
+    const Policy pol(ga, lut);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t N = a.rows;
+    const int g = blockIdx.z;
+    const int ns = a.ns;
+    const int64_t tiles = (N + 15) / 16;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile >= tiles) return;  // (no block barrier below)
+    const int s_begin = blockIdx.y * a.steps_per_block;
+    const int s_end = s_begin + a.steps_per_block < a.steps ? s_begin + a.steps_per_block : a.steps;
+    const float* base = a.w + a.goff[g];
+    const float* fo = a.fp_out + (int64_t)g * N * ns;
+    for (int s = s_begin; s < s_end; ++s) {
+        const float* sc = a.scales + ((int64_t)g * a.steps + s) * gs;
+        const float* sa = a.sacts + ((int64_t)g * a.steps + s) * gs * ns;
+        float total = 0.0f;
+        for (int sub = 0; sub < 4; ++sub) {
+            const int64_t n0 = tile * 16 + sub * R;
+            if (n0 >= N) break;  // uniform
+            const float* wr[R];
+            typename Policy::Stat st[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                wr[i] = base + (n0 + i < N ? n0 + i : N - 1) * a.K;
+                st[i] = pol.stat_init();
+            }
+            for (int64_t k = lane; k < gs; k += 64) {
+                const float c = sc[k];
+#pragma unroll
+                for (int i = 0; i < R; ++i) pol.stat_add(st[i], wr[i][k] * c);
+            }
+            typename Policy::Par par[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) awq_stat_xor(pol, st[i], m);
+                par[i] = pol.compute(st[i]);
+            }
+            for (int j0 = 0; j0 < ns; j0 += 64 * NT) {
+                float qa[R][NT];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) qa[i][t] = 0.0f;
+                for (int64_t k0 = 0; k0 < gs; k0 += 64) {
+                    const int64_t k = k0 + lane;
+                    float dqv[R];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        dqv[i] = 0.0f;
+                        if (k < gs) {
+                            int code;
+                            float v;
+                            pol.quant(wr[i][k] * sc[k], par[i], code, v);
+                            dqv[i] = pol.dq(0, v, par[i]);
+                        }
+                    }
+                    const int kn = gs - k0 < 64 ? (int)(gs - k0) : 64;
+                    const float* xr = sa + k0 * ns + j0 + lane;
+                    for (int kk = 0; kk < kn; ++kk) {
+                        float xv[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) xv[t] = (j0 + t * 64 + lane) < ns ? xr[(int64_t)kk * ns + t * 64] : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dqv[i]), kk));
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) qa[i][t] = fmaf(d, xv[t], qa[i][t]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int col = j0 + t * 64 + lane;
+                        if (col < ns && n0 + i < N) total += fabsf(qa[i][t] - fo[(n0 + i) * ns + col]);
+                    }
+            }
+        }
+        total = lanes_allreduce<64>(total, OpAdd());
+        if (lane == 0) a.partial[((int64_t)g * a.steps + s) * tiles + tile] = total;
+    }
+}
+
+template <typename Policy>
+static int awq_any_launch(const AwqArgs& a, int groups, int64_t gs, hipStream_t s) {
+    const int64_t tiles = (a.rows + 15) / 16;
+    const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)((a.steps + a.steps_per_block - 1) / a.steps_per_block), (unsigned)groups);
+    if (a.ns <= 64)
+        hipLaunchKernelGGL((k_awq_search_any<Policy, 1>), grid, dim3(256), 0, s, a, gs);
+    else if (a.ns <= 128)
+        hipLaunchKernelGGL((k_awq_search_any<Policy, 2>), grid, dim3(256), 0, s, a, gs);
+    else
+        hipLaunchKernelGGL((k_awq_search_any<Policy, 4>), grid, dim3(256), 0, s, a, gs);
+    return launch_status("awq_search (any group size)");
+}
+
 template <typename Policy, int GS>
 static int awq_launch(const AwqArgs& a, int groups, hipStream_t s) {
     const int64_t tiles = (a.rows + 15) / 16;
@@ -750,23 +952,30 @@ static int awq_launch(const AwqArgs& a, int groups, hipStream_t s) {
 
 template <typename Policy>
 static int awq_gs(const AwqArgs& a, int groups, int64_t gs, hipStream_t s) {
+    if (a.ns > 64) return awq_any_launch<Policy>(a, groups, gs, s);
     switch (gs) {
         case 32: return awq_launch<Policy, 32>(a, groups, s);
         case 64: return awq_launch<Policy, 64>(a, groups, s);
         case 128: return awq_launch<Policy, 128>(a, groups, s);
-        default:
-            set_error("awq_search: group size %lld is not one of 32 / 64 / 128", (long long)gs);
-            return NNCF_AMD_ERR_UNSUPPORTED;
+        default: return awq_any_launch<Policy>(a, groups, gs, s);
     }
 }
 
 }  // namespace wc
 
+// Layout of `sacts` for a shape: NT = 1 / 2 / 4 -> the tiled kernel's [groups, steps, group_size, 16, NT]; 0 -> the
+// plain [groups, steps, group_size, n_samples] of the `_any` kernel.
+extern "C" int nncf_amd_awq_sacts_tiles(int64_t group_size, int64_t n_samples) {
+    if (!nncf_amd_se_step_supported(group_size, n_samples)) return 0;
+    return n_samples <= 16 ? 1 : (n_samples <= 32 ? 2 : 4);
+}
+
 extern "C" int nncf_amd_awq_search(const float* weight, int64_t rows, int64_t row_pitch, const int64_t* group_offsets,
                                    int groups, int64_t group_size, const float* scales, int steps, const float* sacts,
                                    const float* fp_out, int64_t n_samples, int mode, float* partial, void* stream) {
     using namespace wc;
-    if (rows < 0 || groups < 0 || steps < 0 || row_pitch < group_size) {
+    if (rows < 0 || groups < 0 || steps < 0 || group_size < 1 || row_pitch < group_size || n_samples < 1 ||
+        n_samples > 0x7fffffff) {
         set_error("awq_search: bad argument");
         return NNCF_AMD_ERR_BAD_ARG;
     }
@@ -775,12 +984,11 @@ extern "C" int nncf_amd_awq_search(const float* weight, int64_t rows, int64_t ro
         set_error("awq_search: NULL buffer");
         return NNCF_AMD_ERR_BAD_ARG;
     }
-    if (!nncf_amd_se_step_supported(group_size, n_samples) || groups > 65535) {
-        set_error("awq_search: group size %lld / %lld samples / %d groups not supported", (long long)group_size,
-                  (long long)n_samples, groups);
+    if (groups > 65535) {
+        set_error("awq_search: more than 65535 groups per launch (%d): split the list", groups);
         return NNCF_AMD_ERR_UNSUPPORTED;
     }
-    if (((uintptr_t)scales | (uintptr_t)sacts) & 15u) {
+    if (nncf_amd_awq_sacts_tiles(group_size, n_samples) != 0 && (((uintptr_t)scales | (uintptr_t)sacts) & 15u)) {
         set_error("awq_search: scales / sacts must be 16-byte aligned");
         return NNCF_AMD_ERR_BAD_ARG;
     }
