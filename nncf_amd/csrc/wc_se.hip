@@ -305,6 +305,273 @@ __global__ __launch_bounds__(kSeThreads) void k_se_step(SeStepArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The tiled step for policies whose unscaled values are exact bf16 numbers (integer codes minus the zero point: |t| <=
+// 255; e2m1 values).  Same ownership as k_se_step (a wave = 16 rows of one group, lane = row x quarter), but
+//   * q_outs = near * (t @ X): the contraction runs on v_mfma_f32_16x16x32_bf16 with t as an exact bf16 operand against
+//     a THREE-WAY bf16 split of X (x = h + m + l exactly: 3 x 8 significand bits), i.e. 3 MFMAs of K = 32 instead of
+//     24 of K = 4; every product is exact in fp32, the sums are fp32 as before.  fp_outs (step 0) the same way: a bf16
+//     weight is one exact operand, an fp32 weight is split like X (9 products);
+//   * both quantization passes use the correctly rounded quotient (quant_n_div) -- straight-line packed fp32 math
+//     instead of the tie test and its divergent redo; the scale is GIVEN here, so a lane first checks that its own
+//     elements are finite and their quotients far from overflow (`se_guard`), else it takes the IEEE divide;
+//   * the ideal scale |w| / (|t| + zero_mask) multiplies by a reciprocal from a small LDS table indexed by |t| (t takes
+//     <= 256 values; entry 0 holds 1 / zero_scale), within 1 ulp of the reference's quotient, instead of an IEEE
+//     divide per element.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_bf16_k32(const i32x4v& a, const i32x4v& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the upper halves of two floats as a bf16 pair (element 0 = lo): exact for values with <= 8 significant bits
+__device__ __forceinline__ int pack_hi16(float lo, float hi) {
+    return (int)__builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x07060302u);
+}
+__device__ __forceinline__ float hi16_of(float x) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & 0xffff0000u);
+}
+
+template <typename Policy>
+struct SeExact16 {
+    static constexpr bool value = false;
+};
+template <int M>
+struct SeExact16<IntPolicyT<M>> {
+    static constexpr bool value = true;
+    static constexpr int kIdx = 1;  // table index = |t| * kIdx
+};
+template <int M>
+struct SeExact16<FloatPolicy<false, M>> {
+    static constexpr bool value = true;
+    static constexpr int kIdx = 2;  // e2m1 magnitudes are multiples of 0.5
+};
+
+template <int M>
+__device__ __forceinline__ void se_guard(const IntPolicyT<M>&, typename IntPolicyT<M>::Par& p, float amax) {
+    if (!(amax * fabsf(p.r) <= 1.2676506002282294e+30f)) p.fast = false;  // inf / huge quotients: the IEEE divide
+}
+template <bool NF4, int M>
+__device__ __forceinline__ void se_guard(const FloatPolicy<NF4, M>&, typename FloatPolicy<NF4, M>::Par&, float) {}
+template <int N, int M>
+__device__ __forceinline__ void se_values_div(const IntPolicyT<M>& pol, const typename IntPolicyT<M>::Par& p, const float* in,
+                                              float* out) {
+    pol.template quant_n_div<N>(p, in, out);
+}
+template <int N, bool NF4, int M>
+__device__ __forceinline__ void se_values_div(const FloatPolicy<NF4, M>& pol, const typename FloatPolicy<NF4, M>::Par& p,
+                                              const float* in, float* out) {
+    se_values<N>(pol, p, in, out);
+}
+
+template <int DT, int GS>
+struct Se16Shape {
+    static constexpr int kWaves = (DT == NNCF_AMD_F32 && GS == 128) ? 12 : 16;
+    static constexpr int kThreads = kWaves * 64;
+    static constexpr int M = GS / 32;                       // MFMAs (K = 32) per operand piece and sample tile
+    static constexpr int kPiece = 4 * M * 1024;             // bytes of one bf16 piece of X (4 sample tiles)
+    static constexpr int kPitch = GS * Elem<DT>::kBytes + 16;
+    static constexpr int kStage = 3 * kPiece;
+    static constexpr int kDsh = kStage + kWaves * 16 * kPitch;
+    static constexpr int kSsh = kDsh + kWaves * 16 * 4;
+    static constexpr int kRtab = kSsh + GS * 4;
+    static constexpr int kLut = kRtab + 256 * 4;
+    static constexpr int kBytes = kLut + kPolicyLds * 4;
+};
+
+// BASE: step 0 (min-max baseline + fp_outs); the search steps (kinds 1, 2) are the other instantiation
+template <typename Policy, int DT, int GS, int NT, bool BASE>
+__global__ __launch_bounds__((Se16Shape<DT, GS>::kThreads)) void k_se_step16(SeStepArgs a) {
+    using SH = Se16Shape<DT, GS>;
+    constexpr int QUART = GS / 4, M = SH::M, THREADS = SH::kThreads;
+    constexpr int KIDX = SeExact16<Policy>::kIdx;
+    extern __shared__ __align__(16) char se16_smem[];
+    char* Bx = se16_smem;  // [piece][tile][m][q][c] x 16 bytes = the 8 bf16 of k = q*QUART + 8m .. +7, sample t*16 + c
+    float* ssh = (float*)(se16_smem + SH::kSsh);
+    float* rtab = (float*)(se16_smem + SH::kRtab);
+    float* lut = (float*)(se16_smem + SH::kLut);
+    Policy::init_shared(lut);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* stage = (float*)(se16_smem + SH::kStage + wave * 16 * SH::kPitch);
+    float* dsh = (float*)(se16_smem + SH::kDsh) + wave * 16;
+    const int64_t g = blockIdx.y, e = blockIdx.z, N = a.rows, G = a.groups;
+    const int ns = a.ns;
+    {
+        const float* xg = a.x + ((e * G + g) * GS) * ns;
+        for (int idx = threadIdx.x; idx < GS * 16 * NT; idx += THREADS) {
+            const int k = idx / (16 * NT), col = idx % (16 * NT);
+            const float x = col < ns ? xg[k * ns + col] : 0.0f;
+            const float h = hi16_of(x), r1 = x - h, m = hi16_of(r1), l = r1 - m;  // exact: 8 + 8 + 8 significand bits
+            const int off = (((((col >> 4) * M + (k % QUART) / 8) * 4 + k / QUART) * 16 + (col & 15)) * 8 + (k & 7)) * 2;
+            *(uint16_t*)(Bx + off) = (uint16_t)(__builtin_bit_cast(uint32_t, h) >> 16);
+            *(uint16_t*)(Bx + SH::kPiece + off) = (uint16_t)(__builtin_bit_cast(uint32_t, m) >> 16);
+            *(uint16_t*)(Bx + 2 * SH::kPiece + off) = (uint16_t)(__builtin_bit_cast(uint32_t, l) >> 16);
+        }
+    }
+    if (threadIdx.x < GS) ssh[threadIdx.x] = !BASE ? a.s[(e * G + g) * GS + threadIdx.x] : 0.0f;
+    if (threadIdx.x < 256)
+        rtab[threadIdx.x] = threadIdx.x == 0 ? 1.0f / a.zero_scale : (float)KIDX / (float)threadIdx.x;
+    __syncthreads();
+    GroupArgs ga = {};
+    ga.mode = a.mode;
+    const Policy pol(ga, lut);
+    const int r = lane & 15, q = lane >> 4;
+    const bool has_zp = a.zp != nullptr;
+    const bool want_pen = a.weight_penalty > 0.0f;  // uniform
+    float* fo = a.fp_outs + ((e * G + g) * N) * ns;
+    const char* bb = Bx + (q * 16 + r) * 16;
+    constexpr int C = QUART < 8 ? QUART : 8;
+    for (int64_t n0 = ((int64_t)blockIdx.x * SH::kWaves + wave) * 16; n0 < N; n0 += (int64_t)gridDim.x * SH::kWaves * 16) {
+        const int64_t row = n0 + r;
+        const int64_t rowc = row < N ? row : N - 1;
+        const int64_t pidx = (e * N + rowc) * G + g;
+        const float sc0 = a.scale0[pidx];
+        const float zsub = has_zp ? a.zp[pidx] : 0.0f;
+        float wv[QUART];
+        se_load_rows<GS, DT>(a.w, wv, stage, n0, N, (e * N) * G + g, G, lane);
+        float amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < QUART; i += 2) amax = max3_abs_raw(amax, wv[i], wv[i + 1]);
+        float near = sc0;
+        if constexpr (!BASE) {
+            // importance_k = (mask_k ? 0 : s_k) / (sum + eps)  (scale_estimation.py:236-247)
+            const uint32_t keep = ~a.zmask[pidx * 4 + q];
+            const float rd = a.rden[pidx];
+            typename Policy::Par pc = se_par(pol, a.kind == 1 ? a.result[pidx] : a.factor * sc0, zsub, has_zp);
+            se_guard(pol, pc, amax);
+            float acc1 = 0.0f;
+#pragma unroll
+            for (int c0 = 0; c0 < QUART; c0 += C) {
+                float val[C], sch[C];
+                se_values_div<C>(pol, pc, wv + c0, val);
+#pragma unroll
+                for (int i = 0; i < C; i += 4) *(float4*)(sch + i) = *(const float4*)(ssh + q * QUART + c0 + i);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const float t = fabsf(val[i] - zsub);
+                    const float rc = rtab[(int)(KIDX == 1 ? t : t * (float)KIDX)];
+                    // bit c0 + i of `keep` spread over the word: the channel's s or 0
+                    const int sel = __builtin_amdgcn_sbfe(keep, c0 + i, 1);
+                    const float sv = __builtin_bit_cast(float, __builtin_bit_cast(int, sch[i]) & sel);
+                    acc1 = fmaf(fabsf(wv[c0 + i]) * rc, sv, acc1);
+                }
+            }
+            acc1 += __shfl_xor(acc1, 16, 64);
+            acc1 += __shfl_xor(acc1, 32, 64);
+            near = (acc1 * rd) * (sc0 / fabsf(sc0));  // scale_sign = scale / |scale|  (scale_estimation.py:264)
+        }
+        // the unscaled quantization with `near` as exact bf16 operands (dq = t * near is only formed for the penalty)
+        typename Policy::Par pn = se_par(pol, near, zsub, has_zp);
+        se_guard(pol, pn, amax);
+        i32x4v Aq[M];
+        float pen = 0.0f;
+#pragma unroll
+        for (int c0 = 0; c0 < QUART; c0 += C) {
+            float val[C];
+            se_values_div<C>(pol, pn, wv + c0, val);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                val[i] = val[i] - zsub;
+                if (want_pen) {
+                    const float d = val[i] * near - wv[c0 + i];
+                    pen += d * d;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < C; i += 2) Aq[(c0 + i) / 8][((c0 + i) & 7) / 2] = pack_hi16(val[i], val[i + 1]);
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (int p = 0; p < 3; ++p) {  // (not unrolled: the 12 * M operand reads would all be hoisted into registers)
+            const char* bp = bb + p * SH::kPiece;
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = mfma_bf16_k32(Aq[m], *(const i32x4v*)(bp + (t * M + m) * 1024), acc[t]);
+        }
+        // fp_outs = w @ X (scale_estimation.py:250), written by step 0 for the later ones: the weight as exact bf16 pieces
+        f32x4 facc[NT];
+        if constexpr (BASE) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) facc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            constexpr int WP = DT == NNCF_AMD_F32 ? 3 : 1;
+#pragma unroll 1
+            for (int wp = 0; wp < WP; ++wp) {
+                i32x4v Aw[M];
+#pragma unroll
+                for (int i = 0; i < QUART; i += 2) {
+                    Aw[i / 8][(i & 7) / 2] = pack_hi16(wv[i], wv[i + 1]);
+                    if (WP > 1) wv[i] -= hi16_of(wv[i]), wv[i + 1] -= hi16_of(wv[i + 1]);  // next piece (exact)
+                }
+#pragma unroll 1
+                for (int p = 0; p < 3; ++p) {
+                    const char* bp = bb + p * SH::kPiece;
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            facc[t] = mfma_bf16_k32(Aw[m], *(const i32x4v*)(bp + (t * M + m) * 1024), facc[t]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t orow = n0 + 4 * q + i;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int col = t * 16 + r;
+                    if (col < ns && orow < N) fo[orow * ns + col] = facc[t][i];
+                }
+            }
+        }
+        // C layout: lane (c = lane % 16, q) holds rows 4q + i (i = 0..3) of sample column t*16 + c; the rows' `near`
+        // sits in lanes 4q + i (quarter 0 of those rows)
+        float sq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t orow = n0 + 4 * q + i;
+            const float near_i = __shfl(near, 4 * q + i, 64);
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 16 + r;
+                float f;
+                if constexpr (BASE) f = (col < ns && orow < N) ? facc[t][i] : 0.0f;
+                else f = (col < ns && orow < N) ? fo[orow * ns + col] : 0.0f;
+                const float d = f - near_i * acc[t][i];
+                sum += (col < ns) ? d * d : 0.0f;
+            }
+            sq[i] = lanes_allreduce<16>(sum, OpAdd());
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dsh[4 * q + i] = sq[i];
+        }
+        if (want_pen) {
+            pen += __shfl_xor(pen, 16, 64);
+            pen += __shfl_xor(pen, 32, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (q == 0 && row < N) {
+            float diff = dsh[r] / (float)ns;
+            if (want_pen) diff = diff + a.weight_penalty * (pen / (float)GS);
+            if constexpr (BASE) {
+                a.best[pidx] = diff;
+                a.result[pidx] = near;
+            } else {
+                const float b = a.best[pidx], rs = a.result[pidx];
+                const float mask = diff > b ? 1.0f : 0.0f;
+                a.best[pidx] = mask * b + (1.0f - mask) * diff;
+                a.result[pidx] = mask * rs + (1.0f - mask) * near;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // dsh and the staging buffer are rewritten by the next tile
+    }
+}
+
 // Any group size / any number of samples (the tiled kernel above takes 32 / 64 / 128 x <= 64): a wave owns R = 4 rows
 // of one group.  Pass 1, lanes stride over the group's elements: zero mask of the min-max quantization and the sum of
 // the unmasked s (the importance of scale_estimation.py:236-247, rebuilt per step: no weight-sized mask is kept),
@@ -507,26 +774,50 @@ __global__ __launch_bounds__(256) void k_se_zero_mask(const void* __restrict__ w
 
 template <typename Policy, int DT, int GS>
 static int se_step_launch(const SeStepArgs& a, int64_t batch, hipStream_t s) {
-    constexpr size_t lds_bytes = (size_t)se_lds_floats<GS>() * sizeof(float);
+    // blocks per group column: one resident set (one block per CU), at most one per set of row tiles a block's
+    // waves take at a time; the X slice of the group is staged once per block
+    auto grid_of = [&](int waves) {
+        const int64_t tile_sets = (a.rows + 16 * waves - 1) / (16 * waves);
+        int64_t per_col = (256 + a.groups * batch - 1) / (a.groups * batch);
+        if (per_col > tile_sets) per_col = tile_sets;
+        if (per_col < 1) per_col = 1;
+        return dim3((unsigned)per_col, (unsigned)a.groups, (unsigned)batch);
+    };
     static OncePerDevice attr_once;
-    if (attr_once.first_on_device() != 0) {
-        if (hipFuncSetAttribute((const void*)k_se_step<Policy, DT, GS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_se_step<Policy, DT, GS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
-            attr_once.forget_current();
-            return launch_status("se_step attribute");
+    if constexpr (SeExact16<Policy>::value) {
+        using SH = Se16Shape<DT, GS>;
+        if (attr_once.first_on_device() != 0) {
+            if (hipFuncSetAttribute((const void*)k_se_step16<Policy, DT, GS, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::kBytes) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_se_step16<Policy, DT, GS, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::kBytes) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_se_step16<Policy, DT, GS, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::kBytes) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_se_step16<Policy, DT, GS, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::kBytes) != hipSuccess) {
+                attr_once.forget_current();
+                return launch_status("se_step attribute");
+            }
         }
+        const dim3 grid = grid_of(SH::kWaves), block(SH::kThreads);
+        if (a.ns <= 32 && a.kind == 0)
+            hipLaunchKernelGGL((k_se_step16<Policy, DT, GS, 2, true>), grid, block, SH::kBytes, s, a);
+        else if (a.ns <= 32)
+            hipLaunchKernelGGL((k_se_step16<Policy, DT, GS, 2, false>), grid, block, SH::kBytes, s, a);
+        else if (a.kind == 0)
+            hipLaunchKernelGGL((k_se_step16<Policy, DT, GS, 4, true>), grid, block, SH::kBytes, s, a);
+        else
+            hipLaunchKernelGGL((k_se_step16<Policy, DT, GS, 4, false>), grid, block, SH::kBytes, s, a);
+    } else {
+        constexpr size_t lds_bytes = (size_t)se_lds_floats<GS>() * sizeof(float);
+        if (attr_once.first_on_device() != 0) {
+            if (hipFuncSetAttribute((const void*)k_se_step<Policy, DT, GS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_se_step<Policy, DT, GS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+                attr_once.forget_current();
+                return launch_status("se_step attribute");
+            }
+        }
+        if (a.ns <= 32)
+            hipLaunchKernelGGL((k_se_step<Policy, DT, GS, 2>), grid_of(kSeWaves), dim3(kSeThreads), lds_bytes, s, a);
+        else
+            hipLaunchKernelGGL((k_se_step<Policy, DT, GS, 4>), grid_of(kSeWaves), dim3(kSeThreads), lds_bytes, s, a);
     }
-    // blocks per group column: one resident set (one block of kSeWaves waves per CU), at most one per kSeWaves row
-    // tiles; the X slice of the group is staged once per block
-    const int64_t tile_sets = (a.rows + 16 * kSeWaves - 1) / (16 * kSeWaves);
-    int64_t per_col = (256 + a.groups * batch - 1) / (a.groups * batch);  // one resident block per CU
-    if (per_col > tile_sets) per_col = tile_sets;
-    if (per_col < 1) per_col = 1;
-    const dim3 grid((unsigned)per_col, (unsigned)a.groups, (unsigned)batch);
-    if (a.ns <= 32)
-        hipLaunchKernelGGL((k_se_step<Policy, DT, GS, 2>), grid, dim3(kSeThreads), lds_bytes, s, a);
-    else
-        hipLaunchKernelGGL((k_se_step<Policy, DT, GS, 4>), grid, dim3(kSeThreads), lds_bytes, s, a);
     return launch_status("se_step");
 }
 
