@@ -353,10 +353,44 @@ __device__ __forceinline__ void se_guard(const IntPolicyT<M>&, typename IntPolic
 }
 template <bool NF4, int M>
 __device__ __forceinline__ void se_guard(const FloatPolicy<NF4, M>&, typename FloatPolicy<NF4, M>::Par&, float) {}
+// IntPolicyT::quant_n_div restated for this kernel's issue order: the five multiply-adds of the correctly rounded
+// quotient (see wc_int_policy.h) run stage by stage over the N / 2 element pairs, so consecutive packed instructions
+// are independent (a dependent v_pk_fma chain costs a wait state per link), the zero point is always added (+0 for
+// symmetric modes: rne and the clip see the same value) and the choice between this path and the IEEE divide is made
+// once per WAVE (any lane whose group is "not fast" sends the wave through the divide, which is exact for everyone).
 template <int N, int M>
 __device__ __forceinline__ void se_values_div(const IntPolicyT<M>& pol, const typename IntPolicyT<M>::Par& p, const float* in,
                                               float* out) {
-    pol.template quant_n_div<N>(p, in, out);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    static_assert(N % 2 == 0, "pairs of elements");
+    if (__builtin_amdgcn_ballot_w64(!p.fast) != 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) out[i] = int_quant(in[i], p.scale, p.zpf, p.has_zp, pol.m);
+        return;
+    }
+    const f32x2 r = {p.r, p.r}, ns = {-p.scale, -p.scale};
+    const float zf = p.has_zp ? p.zpf : 0.0f;
+    const f32x2 z = {zf, zf};
+    f32x2 w[N / 2], q[N / 2], res[N / 2];
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) w[j] = f32x2{in[2 * j], in[2 * j + 1]};
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) q[j] = w[j] * r;
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) res[j] = __builtin_elementwise_fma(q[j], ns, w[j]);
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) q[j] = __builtin_elementwise_fma(res[j], r, q[j]);
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) res[j] = __builtin_elementwise_fma(q[j], ns, w[j]);
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) q[j] = __builtin_elementwise_fma(res[j], r, q[j]);
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) q[j] = q[j] + z;
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+        out[2 * j] = __builtin_amdgcn_fmed3f(rintf(q[j].x), pol.m.level_low, pol.m.level_high);
+        out[2 * j + 1] = __builtin_amdgcn_fmed3f(rintf(q[j].y), pol.m.level_low, pol.m.level_high);
+    }
 }
 template <int N, bool NF4, int M>
 __device__ __forceinline__ void se_values_div(const FloatPolicy<NF4, M>& pol, const typename FloatPolicy<NF4, M>::Par& p,
@@ -364,9 +398,27 @@ __device__ __forceinline__ void se_values_div(const FloatPolicy<NF4, M>& pol, co
     se_values<N>(pol, p, in, out);
 }
 
+// acc[t] += A[m] x (piece p of X, sample tile t) over the 3 pieces and M k-blocks.  The piece loop stays rolled: fully
+// unrolled the compiler hoists all 12 * M operand reads (192 registers) in front of the first MFMA.  (Measured and
+// dropped: a rolling / double-buffered operand pipeline behind scheduling barriers and an early request of the
+// tile's fp_outs -- both cost more in registers than they hide in latency, 108 / 137 us against 100 us per step on a
+// 14336 x 4096 weight.)
+template <typename SH, int NT>
+__device__ __forceinline__ void se_mfma_pipeline(const i32x4v* A, const char* bb, f32x4* acc) {
+    constexpr int M = SH::M;
+#pragma unroll 1
+    for (int p = 0; p < 3; ++p) {
+        const char* bp = bb + p * SH::kPiece;
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16_k32(A[m], *(const i32x4v*)(bp + (t * M + m) * 1024), acc[t]);
+    }
+}
+
 template <int DT, int GS>
 struct Se16Shape {
-    static constexpr int kWaves = (DT == NNCF_AMD_F32 && GS == 128) ? 12 : 16;
+        static constexpr int kWaves = GS == 128 ? 12 : 16;  // 170 / 128 registers per lane (16 waves at GS 128: spills, +12 %)
     static constexpr int kThreads = kWaves * 64;
     static constexpr int M = GS / 32;                       // MFMAs (K = 32) per operand piece and sample tile
     static constexpr int kPiece = 4 * M * 1024;             // bytes of one bf16 piece of X (4 sample tiles)
@@ -394,9 +446,29 @@ __global__ __launch_bounds__((Se16Shape<DT, GS>::kThreads)) void k_se_step16(SeS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* stage = (float*)(se16_smem + SH::kStage + wave * 16 * SH::kPitch);
     float* dsh = (float*)(se16_smem + SH::kDsh) + wave * 16;
-    const int64_t g = blockIdx.y, e = blockIdx.z, N = a.rows, G = a.groups;
+    const int64_t e = blockIdx.z, N = a.rows, G = a.groups;
     const int ns = a.ns;
-    {
+    if (threadIdx.x < 256)
+        rtab[threadIdx.x] = threadIdx.x == 0 ? 1.0f / a.zero_scale : (float)KIDX / (float)threadIdx.x;
+    GroupArgs ga = {};
+    ga.mode = a.mode;
+    const Policy pol(ga, lut);
+    const int r = lane & 15, q = lane >> 4;
+    const bool has_zp = a.zp != nullptr;
+    const bool want_pen = a.weight_penalty > 0.0f;  // uniform
+    const char* bb = Bx + (q * 16 + r) * 16;
+    constexpr int C = QUART < 8 ? QUART : 8;
+    // The 16-row tiles of the weight, group column by group column, are cut into gridDim.x equal runs: every block
+    // does the same number of tiles whatever the shape (a grid of whole columns left the last round of blocks half
+    // empty: 336 blocks on 256 CUs for a 4096 x 14336 weight), and re-stages the X slice when its run crosses into
+    // the next column (at most twice for G <= 256).
+    const int64_t tpc = (N + 15) / 16, total = G * tpc;
+    const int64_t run_lo = total * blockIdx.x / gridDim.x, run_hi = total * (blockIdx.x + 1) / gridDim.x;
+    for (int64_t seg = run_lo; seg < run_hi;) {
+      const int64_t g = seg / tpc;
+      const int64_t seg_end = (g + 1) * tpc < run_hi ? (g + 1) * tpc : run_hi;
+      __syncthreads();  // the previous column's readers are done with Bx / ssh
+      {
         const float* xg = a.x + ((e * G + g) * GS) * ns;
         for (int idx = threadIdx.x; idx < GS * 16 * NT; idx += THREADS) {
             const int k = idx / (16 * NT), col = idx % (16 * NT);
@@ -407,21 +479,12 @@ __global__ __launch_bounds__((Se16Shape<DT, GS>::kThreads)) void k_se_step16(SeS
             *(uint16_t*)(Bx + SH::kPiece + off) = (uint16_t)(__builtin_bit_cast(uint32_t, m) >> 16);
             *(uint16_t*)(Bx + 2 * SH::kPiece + off) = (uint16_t)(__builtin_bit_cast(uint32_t, l) >> 16);
         }
-    }
-    if (threadIdx.x < GS) ssh[threadIdx.x] = !BASE ? a.s[(e * G + g) * GS + threadIdx.x] : 0.0f;
-    if (threadIdx.x < 256)
-        rtab[threadIdx.x] = threadIdx.x == 0 ? 1.0f / a.zero_scale : (float)KIDX / (float)threadIdx.x;
-    __syncthreads();
-    GroupArgs ga = {};
-    ga.mode = a.mode;
-    const Policy pol(ga, lut);
-    const int r = lane & 15, q = lane >> 4;
-    const bool has_zp = a.zp != nullptr;
-    const bool want_pen = a.weight_penalty > 0.0f;  // uniform
-    float* fo = a.fp_outs + ((e * G + g) * N) * ns;
-    const char* bb = Bx + (q * 16 + r) * 16;
-    constexpr int C = QUART < 8 ? QUART : 8;
-    for (int64_t n0 = ((int64_t)blockIdx.x * SH::kWaves + wave) * 16; n0 < N; n0 += (int64_t)gridDim.x * SH::kWaves * 16) {
+        if (threadIdx.x < GS) ssh[threadIdx.x] = !BASE ? a.s[(e * G + g) * GS + threadIdx.x] : 0.0f;
+      }
+      __syncthreads();
+      float* fo = a.fp_outs + ((e * G + g) * N) * ns;
+      for (int64_t tile = seg + wave; tile < seg_end; tile += SH::kWaves) {
+        const int64_t n0 = (tile - g * tpc) * 16;
         const int64_t row = n0 + r;
         const int64_t rowc = row < N ? row : N - 1;
         const int64_t pidx = (e * N + rowc) * G + g;
@@ -483,15 +546,7 @@ __global__ __launch_bounds__((Se16Shape<DT, GS>::kThreads)) void k_se_step16(SeS
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-        for (int p = 0; p < 3; ++p) {  // (not unrolled: the 12 * M operand reads would all be hoisted into registers)
-            const char* bp = bb + p * SH::kPiece;
-#pragma unroll
-            for (int m = 0; m < M; ++m)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = mfma_bf16_k32(Aq[m], *(const i32x4v*)(bp + (t * M + m) * 1024), acc[t]);
-        }
+        se_mfma_pipeline<SH, NT>(Aq, bb, acc);
         // fp_outs = w @ X (scale_estimation.py:250), written by step 0 for the later ones: the weight as exact bf16 pieces
         f32x4 facc[NT];
         if constexpr (BASE) {
@@ -506,15 +561,7 @@ __global__ __launch_bounds__((Se16Shape<DT, GS>::kThreads)) void k_se_step16(SeS
                     Aw[i / 8][(i & 7) / 2] = pack_hi16(wv[i], wv[i + 1]);
                     if (WP > 1) wv[i] -= hi16_of(wv[i]), wv[i + 1] -= hi16_of(wv[i + 1]);  // next piece (exact)
                 }
-#pragma unroll 1
-                for (int p = 0; p < 3; ++p) {
-                    const char* bp = bb + p * SH::kPiece;
-#pragma unroll
-                    for (int m = 0; m < M; ++m)
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            facc[t] = mfma_bf16_k32(Aw[m], *(const i32x4v*)(bp + (t * M + m) * 1024), facc[t]);
-                }
+                se_mfma_pipeline<SH, NT>(Aw, bb, facc);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -569,6 +616,8 @@ __global__ __launch_bounds__((Se16Shape<DT, GS>::kThreads)) void k_se_step16(SeS
             }
         }
         __builtin_amdgcn_wave_barrier();  // dsh and the staging buffer are rewritten by the next tile
+      }
+      seg = seg_end;
     }
 }
 
@@ -795,7 +844,11 @@ static int se_step_launch(const SeStepArgs& a, int64_t batch, hipStream_t s) {
                 return launch_status("se_step attribute");
             }
         }
-        const dim3 grid = grid_of(SH::kWaves), block(SH::kThreads);
+        // equal runs of tiles over one resident set of blocks (one block per CU)
+        const int64_t total = a.groups * ((a.rows + 15) / 16);
+        int64_t nb = 256 / batch > 0 ? 256 / batch : 1;
+        if (nb > (total + SH::kWaves - 1) / SH::kWaves) nb = (total + SH::kWaves - 1) / SH::kWaves;
+        const dim3 grid((unsigned)nb, 1, (unsigned)batch), block(SH::kThreads);
         if (a.ns <= 32 && a.kind == 0)
             hipLaunchKernelGGL((k_se_step16<Policy, DT, GS, 2, true>), grid, block, SH::kBytes, s, a);
         else if (a.ns <= 32)
