@@ -244,6 +244,62 @@ def quantize_node_weight(weight: torch.Tensor, inputs: List[torch.Tensor], confi
     return torch.stack(qs), torch.stack(scs), (torch.stack(zps) if None not in zps else None)
 
 
+def quantize_units(units, config: WeightCompressionConfig, damp_percent: float = 0.1, block_size: int = 128,
+                   overlap: bool = False, on_weight=None):
+    """GPTQ over a sequence of independent units (gptq.py:118-171 for nodes that come with their own activations: the
+    Linears reading one activation share ONE Hessian and ONE Hinv).  `units` yields (inputs, {name: weight [N, K]});
+    returns {name: (quantized fp32 [N, K], scale, zero_point | None)} -- or whatever `on_weight(name, weight, q, scale,
+    zp)` returns for each weight (e.g. the packed codes, so that the fp32 result does not stay alive).
+
+    overlap: two HIP streams -- the Hessian of unit i + 1 (MFMA-bound, fills the chip) is issued on its own stream
+    BEFORE the host starts on unit i's Hinv and column sweeps, whose chains of small dependent kernels leave most of
+    the chip idle.  Same arithmetic (same kernels, same order within a stream).  MEASURED on one Llama-3-70B layer
+    (tools/bench_configs.py c4, A/B/A/B): 612 / 606 / 611 / 608 ms -- the SYRK's one-wave-per-SIMD blocks leave the
+    second queue no room on a CU until they retire, so the chains stretch by what the overlap saves; off by default."""
+    config = as_config(config)
+    out = {}
+    it = iter(units)
+    dev = None
+    side = main = None
+
+    def start_hessian(unit):
+        nonlocal dev, side, main
+        inputs, weights = unit
+        if dev is None:
+            dev = inputs[0].device
+            if overlap:
+                main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+        if not overlap:
+            return calculate_hessian(inputs)[0], None, weights
+        side.wait_stream(main)  # the inputs were produced on the caller's stream
+        with torch.cuda.stream(side):
+            hessian = calculate_hessian(inputs)[0]
+            done = torch.cuda.Event()
+            done.record(side)
+        return hessian, done, weights
+
+    nxt = next(it, None)
+    pending = start_hessian(nxt) if nxt is not None else None
+    while pending is not None:
+        hessian, done, weights = pending
+        nxt = next(it, None)
+        pending = start_hessian(nxt) if nxt is not None else None  # queued before this unit's host-synchronising Hinv
+        if done is not None:
+            main.wait_event(done)
+            hessian.record_stream(main)
+        hinv, dead = prepare_hinv(hessian, damp_percent)
+        del hessian
+        for name, w in weights.items():
+            q, scale, zp = quantize_weights(None, w.to(torch.float32).contiguous().clone() if w.dtype == torch.float32
+                                            else w.to(torch.float32).contiguous(), config, hinv=hinv, dead=dead,
+                                            damp_percent=damp_percent, block_size=block_size)
+            out[name] = on_weight(name, w, q, scale, zp) if on_weight is not None else (q, scale, zp)
+        del hinv
+    if side is not None:
+        main.wait_stream(side)
+    return out
+
+
 SUPER_BLOCKS = 8  # 128-column blocks per far trailing update (see quantize_weights)
 
 

@@ -116,8 +116,29 @@ def c4(args):
                 q.to(torch.bfloat16), (1,), cfg, CompressedWeight(None, sc, zp)))
         del hinv
     total = sum(ph.ms.values())
+    # the same layer through the product's unit pipeline (gptq.quantize_units): Hessian of unit i + 1 on a second
+    # stream under unit i's Hinv and sweeps; activations of all four units resident before the clock starts
+    layer_wall = {}
+    if not args.no_pipeline:
+        all_acts = {k: make_acts(args.samples, args.tokens, k, outliers=False) for k in (H, I)}
+
+        def units():
+            for key, k, names in groups:
+                yield all_acts[k], {n: W[n] for n in names}
+
+        def pack(name, w, q, sc, zp):
+            return wl.compress_weight_packed(q.to(torch.bfloat16), (1,), cfg, CompressedWeight(None, sc, zp)).tensor
+
+        for mode, ov in (("sequential", False), ("two_streams", True), ("sequential_again", False), ("two_streams_again", True)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = gptq.quantize_units(units(), cfg, overlap=ov, on_weight=pack)
+            torch.cuda.synchronize()
+            layer_wall[mode] = round((time.perf_counter() - t0) * 1e3, 2)
+            del res
     return {"config": "c4: Llama-3-70B layer, %s g64, gptq, %d x %d tokens bf16" % (args.mode, args.samples, args.tokens),
             "phases_ms": {k: round(v, 3) for k, v in ph.ms.items()}, "layer_ms": round(total, 3),
+            "layer_wall_ms_quantize_units": layer_wall,
             "hessian_TFLOPs_real": round(flops / ph.ms["hessian accumulation (MFMA SYRK)"] / 1e9, 1),
             "model_s_80_layers_x_layer_time_1gpu": round(total * 80 / 1e3, 2),
             "model_s_8gpus_layer_sharded": round(total * 10 / 1e3, 2),
@@ -188,6 +209,7 @@ if __name__ == "__main__":
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--tokens", type=int, default=2048)
     ap.add_argument("--mode", default="int4_sym")
+    ap.add_argument("--no-pipeline", action="store_true", help="c4: skip the quantize_units wall-time legs")
     ap.add_argument("--cpu-baseline", action="store_true", help="add the oracle's CPU time on a reduced sample, extrapolated")
     a = ap.parse_args()
     res = {"c3": c3, "c4": c4}[a.which](a)
