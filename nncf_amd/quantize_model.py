@@ -897,14 +897,79 @@ def _decompressor_classes():
 _DECOMPRESSORS = _decompressor_classes()
 
 
-def save_compressed(model: nn.Module, path: str) -> None:
+def _reference_node_name(model: nn.Module, module_name: str, counters: Dict[str, int]) -> str:
+    """Name the reference's tracer gives the call of an nn.Linear: the attribute names on the way to the module
+    joined by "/", with nn.ModuleList containers and their indices left out (they are never called, so they do not
+    show in the scope), then "/linear/<n>" with n counting the calls of that scope in model order -- e.g.
+    blocks.2.mlp.fc2 -> "mlp/fc2/linear/0" when only block 2 has an fc2 [probed: tests/golden/model_tiny.npz].
+    Other containers / call patterns are parity unpinned."""
+    parts, cur, skip = [], model, False
+    for comp in module_name.split("."):
+        nxt = getattr(cur, comp) if not comp.isdigit() else cur[int(comp)]
+        if isinstance(nxt, nn.ModuleList):
+            skip = True  # the container's own name
+        elif skip and comp.isdigit():
+            skip = False  # the index inside it
+        else:
+            parts.append(comp)
+            skip = False
+        cur = nxt
+    scope = "/".join(parts)
+    n = counters.get(scope, 0)
+    counters[scope] = n + 1
+    return f"{scope}/linear/{n}"
+
+
+def nncf_state_dict(model: nn.Module) -> Dict[str, torch.Tensor]:
+    """state_dict of a model compressed by this module under the REFERENCE's keys (what `model.state_dict()` holds
+    after the reference's nncf.compress_weights on the Torch backend [probed, SURVEY section 5 / 8 f4]; written by
+    function_hook/serialization.py + the hook storage, torch_backend.py:352-422, layers.py:1303-1460):
+        <module>.weight                                                   packed codes (uint8 / int8)
+        __nncf_hooks.post_hooks.<module with ':' for '.'>:weight__0.0._scale          fp16 (E8M0 bytes for MXFP4)
+        __nncf_hooks.post_hooks.<...>:weight__0.0._zero_point                       packed / uint8 zero points
+        __nncf_hooks.pre_hooks.<node name>__0.0._scale_value                        AWQ activation scale
+    Tensors are the ones the modules hold (no copies); weights shared by several modules appear under each module's
+    `.weight` key and carry ONE hook, under the first module's name, as the reference stores them."""
+    out: Dict[str, torch.Tensor] = {}
+    owners: Dict[int, str] = {}
+    counters: Dict[str, int] = {}
+    mapped = set()
+    for name, mod in model.named_modules():
+        if parametrize.is_parametrized(mod, "weight"):
+            plist = mod.parametrizations.weight
+            dec = plist[0]
+            prefix = f"{name}.parametrizations.weight."
+            mapped.update((prefix + "original", prefix + "0._scale", prefix + "0._zero_point"))
+            out[f"{name}.weight"] = plist.original.detach()
+            if owners.setdefault(id(plist.original), name) == name:
+                hook = "__nncf_hooks.post_hooks." + name.replace(".", ":") + ":weight__0.0."
+                out[hook + "_scale"] = dec._scale
+                if hasattr(dec, "_zero_point"):
+                    out[hook + "_zero_point"] = dec._zero_point
+        if isinstance(getattr(mod, "awq_input_scale", None), SQMultiply):
+            mapped.add(f"{name}.awq_input_scale._scale_value")
+            node = _reference_node_name(model, name, counters)
+            out[f"__nncf_hooks.pre_hooks.{node}__0.0._scale_value"] = mod.awq_input_scale._scale_value
+    for k, v in model.state_dict().items():
+        if k not in mapped:
+            out[k] = v
+    return out
+
+
+def save_compressed(model: nn.Module, path: str, layout: str = "native") -> None:
     """Writes the compressed model as ONE safetensors file: the model's state_dict (packed weights, fp16 / E8M0
     scales, packed zero points, AWQ activation scales, everything left uncompressed) plus a JSON header that says
     which module carries which decompressor.  The tensors are the reference's torch DQ storage format
-    (layers.py:1303-1460, quantize_functions.py:417-461: nibble pairs low-first, +8 bias for INT4_SYM)."""
+    (layers.py:1303-1460, quantize_functions.py:417-461: nibble pairs low-first, +8 bias for INT4_SYM).
+    layout "native": this build's module tree (`<module>.parametrizations.weight.*`); layout "nncf": the
+    reference's own keys (`nncf_state_dict`), so that the file's tensors are what a model compressed by the reference
+    stores; `load_compressed` reads both."""
     import json
 
     from safetensors.torch import save_file
+
+    if layout not in ("native", "nncf"):
+        raise ValueError(f"save_compressed: layout must be 'native' or 'nncf', got {layout!r}")
 
     entries, groups = {}, {}
     for name, mod in model.named_modules():
@@ -922,15 +987,30 @@ def save_compressed(model: nn.Module, path: str) -> None:
             entries[name] = e
     sq = [name for name, mod in model.named_modules() if isinstance(getattr(mod, "awq_input_scale", None), SQMultiply)]
     tensors, seen, aliases = {}, {}, {}
-    for k, v in model.state_dict().items():
+    source = model.state_dict() if layout == "native" else nncf_state_dict(model)
+    for k, v in source.items():
         key = (v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.storage_offset(), v.dtype)
         if v.numel() and key in seen:  # tied tensors are stored once (safetensors refuses shared storage)
             aliases[k] = seen[key]
             continue
         seen[key] = k
         tensors[k] = v.detach().contiguous()
-    save_file(tensors, path, metadata={"nncf_amd_weight_compression": json.dumps(
-        {"weights": entries, "awq": sq, "aliases": aliases})})
+    header = {"weights": entries, "awq": sq, "aliases": aliases, "layout": layout}
+    if layout == "nncf":  # reference key -> this build's key, for load_compressed
+        native = {}
+        counters: Dict[str, int] = {}
+        for name in entries:
+            hook = "__nncf_hooks.post_hooks." + name.replace(".", ":") + ":weight__0.0."
+            prefix = f"{name}.parametrizations.weight."
+            native[f"{name}.weight"] = prefix + "original"
+            native[hook + "_scale"] = prefix + "0._scale"
+            native[hook + "_zero_point"] = prefix + "0._zero_point"
+        for name, mod in model.named_modules():
+            if isinstance(getattr(mod, "awq_input_scale", None), SQMultiply):
+                node = _reference_node_name(model, name, counters)
+                native[f"__nncf_hooks.pre_hooks.{node}__0.0._scale_value"] = f"{name}.awq_input_scale._scale_value"
+        header["native_keys"] = {k: v for k, v in native.items() if k in tensors or k in aliases}
+    save_file(tensors, path, metadata={"nncf_amd_weight_compression": json.dumps(header)})
 
 
 def load_compressed(model: nn.Module, path: str) -> nn.Module:
@@ -944,6 +1024,10 @@ def load_compressed(model: nn.Module, path: str) -> nn.Module:
     with safe_open(path, framework="pt", device=str(device)) as fh:
         header = json.loads(fh.metadata()["nncf_amd_weight_compression"])
         tensors = {k: fh.get_tensor(k) for k in fh.keys()}
+    if header.get("layout") == "nncf":  # back to this build's keys
+        native = header["native_keys"]
+        tensors = {native.get(k, k): v for k, v in tensors.items()}
+        header["aliases"] = {native.get(k, k): native.get(v, v) for k, v in header.get("aliases", {}).items()}
     mods = dict(model.named_modules())
     made: Dict[str, Tuple[nn.Parameter, nn.Module]] = {}
     for name, e in header["weights"].items():

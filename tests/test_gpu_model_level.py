@@ -348,6 +348,78 @@ def test_save_and_load_compressed(name, tmp_path):
     assert np.array_equal(again, logits)
 
 
+@pytest.mark.parametrize("layout", ["native", "nncf"])
+def test_save_and_load_compressed_layouts(layout, tmp_path):
+    from nncf_amd.quantize_model import load_compressed, save_compressed
+
+    name = "int4_asym_g32_r08_awq_se"
+    model, per, logits = _run_tiny(name)
+    path = str(tmp_path / "m.safetensors")
+    save_compressed(model, path, layout=layout)
+    mkw, _ = TINY_CONFIGS[name]
+    fresh = make_tiny_lm(seed=7, **mkw).cuda()
+    load_compressed(fresh, path)
+    with torch.no_grad():
+        again = fresh(tiny_lm_dataset()[0].cuda()).float().cpu().numpy()
+    assert np.array_equal(again, logits)
+    with pytest.raises(ValueError):
+        save_compressed(model, path, layout="gguf")
+
+
+@pytest.mark.parametrize("name", DATA_FREE + ["int4_asym_g32_awq", "int4_asym_g32_r08_awq_se"])
+def test_export_in_the_reference_state_dict_layout(name, tiny_golden, tmp_path):
+    """SURVEY 8 f4 [probed layout]: `nncf_state_dict` / `save_compressed(layout="nncf")` emit the keys the reference's
+    compressed model holds -- packed `<module>.weight`, `__nncf_hooks.post_hooks.<mod:with:colons>:weight__0.0._scale /
+    ._zero_point`, `__nncf_hooks.pre_hooks.<node>__0.0._scale_value` -- parsed here exactly as tools/gen_golden_model.py
+    parsed the reference's state_dict when it wrote the fixture.  Data-free configurations: same key set, same bytes;
+    AWQ configurations (statistics from a GPU forward): same key set incl. the pre-hook's node name, scales close."""
+    from safetensors import safe_open
+
+    from nncf_amd.quantize_model import nncf_state_dict, save_compressed
+
+    z, meta = tiny_golden
+    model, per, _ = _run_tiny(name)
+    sd = nncf_state_dict(model)
+    path = str(tmp_path / "ref_layout.safetensors")
+    save_compressed(model, path, layout="nncf")
+    with safe_open(path, framework="pt", device="cpu") as fh:
+        on_disk = set(fh.keys())
+        aliases = json.loads(fh.metadata()["nncf_amd_weight_compression"])["aliases"]
+    assert on_disk | set(aliases) == set(sd)
+    assert not any(".parametrizations." in k or "awq_input_scale" in k for k in sd)
+    found, awq = {}, {}
+    for k, v in sd.items():  # the harvest of tools/gen_golden_model.py, on OUR dict
+        if k.startswith("__nncf_hooks.post_hooks.") and (k.endswith("._scale") or k.endswith("._zero_point")):
+            mid = k.split(".")[2]
+            node = mid.rsplit("__", 1)[0]
+            assert node.endswith(":weight"), k
+            mod = node[: -len(":weight")].replace(":", ".")
+            found.setdefault(mod, {})["s" if k.endswith("._scale") else "z"] = v.cpu().numpy()
+        elif k.startswith("__nncf_hooks.pre_hooks.") and k.endswith("._scale_value"):
+            awq[k.split(".")[2]] = v.cpu().numpy()
+    for mod in found:
+        found[mod]["w"] = sd[mod + ".weight"].cpu().numpy()
+    assert sorted(found) == meta[name]["modules"]
+    assert sorted(awq) == meta[name]["awq_keys"]
+    exact = name in DATA_FREE
+    for mod, d in found.items():
+        for kind, v in d.items():
+            ref = z[f"{name}|{mod}|{kind}"]
+            assert v.dtype == ref.dtype and v.shape == ref.shape, (mod, kind, v.dtype, ref.dtype, v.shape, ref.shape)
+            if exact:
+                assert np.array_equal(v.view(np.uint8), ref.view(np.uint8)), (name, mod, kind)
+        assert f"{name}|{mod}|z" not in z.files or "z" in d
+    for key, v in awq.items():
+        ref = z[f"{name}|awq|{key}"]
+        assert v.shape == ref.shape and v.dtype == ref.dtype
+        np.testing.assert_allclose(v.astype(np.float32), ref.astype(np.float32), rtol=1e-4)
+    # everything that is not a compressed weight keeps its own key and value
+    own = model.state_dict()
+    plain = {k for k in sd if k in own}
+    assert plain and all(torch.equal(sd[k], own[k]) for k in plain)
+    assert all(k.startswith("__nncf_hooks.") or k.endswith(".weight") for k in sd if k not in own)
+
+
 def test_statistics_cache_is_reused(tmp_path):
     """with `statistics_path` the calibration statistics are written once and a second compression
     (here: another algorithm mix over the same statistics) does not run the calibration set again."""
