@@ -140,7 +140,9 @@ int nncf_amd_int_quant_error_batched(int n, const void* const* weights_host, int
  * GPU, held until the process ends), so outer * inner is limited to NNCF_AMD_STATIC_ERR_MAX_CHANNELS; beyond that the
  * call returns NNCF_AMD_ERR_WORKSPACE and nncf_amd_int_quant_error with a caller workspace is the way.  Same
  * kernels, same result bits as nncf_amd_int_quant_error.  All calls on one GPU share that array: calls that overlap
- * on one GPU (different streams) race; calls on one stream, or on different GPUs, do not.
+ * on one GPU (different streams) race; calls on one stream, or on different GPUs, do not.  The array's address is
+ * looked up for the CURRENT device (hipGetDevice) at the call: the current device must be the one `stream` and the
+ * buffers belong to.
  */
 #define NNCF_AMD_STATIC_ERR_MAX_CHANNELS 262144
 int nncf_amd_int_quant_error_static(const void* weight, int w_dtype, int64_t outer, int64_t r, int64_t inner,

@@ -24,6 +24,7 @@ from nncf_amd.statistics import WCTensorStatistic, activations_to_wc_statistics
 HESSIAN_CHUNK_TOKENS = 32768  # tokens per SYRK launch: the MFMA kernel reaches its rate from ~16k tokens on
 HESSIAN_CHUNK_BYTES = 1 << 30
 HESSIAN_LIST_MAX_TOKENS = 262144  # the item-list kernel copies nothing: the buffered items are only kept referenced
+HESSIAN_LIST_MAX_BYTES = 4 << 30
 
 
 def _list_chunk_tokens(k: int) -> int:
@@ -62,7 +63,10 @@ class HessianAccumulator:
         self._buf_tokens += x2d.shape[0]
         self._buf_bs += batch_size
         if x2d.dtype != torch.float32 and self.k >= 2048:  # the item-list kernel (flush): no concatenation copy
-            if self._buf_tokens >= self._list_tokens:
+            # nothing is copied, but the buffered items stay referenced: bound them in bytes as well (K = 28672 bf16:
+            # 4 GiB = 75k tokens per launch, far beyond where the kernel's rate has levelled off)
+            if (self._buf_tokens >= self._list_tokens
+                    or self._buf_tokens * self.k * x2d.element_size() >= HESSIAN_LIST_MAX_BYTES):
                 self.flush()
         elif (self._buf_tokens >= self._chunk_tokens
                 or self._buf_tokens * self.k * x2d.element_size() >= HESSIAN_CHUNK_BYTES):
@@ -77,6 +81,8 @@ class HessianAccumulator:
 
         self.nsamples += self._buf_bs
         first = self._buf[0]
+        if any(b.dtype != first.dtype for b in self._buf):  # add() flushes on a dtype change; the kernel reads ONE type
+            raise RuntimeError("HessianAccumulator: buffered items of different dtypes")
         if len(self._buf) > 1 and first.dtype != torch.float32 and self.k >= 2048:
             # the MFMA kernel walks the list of items itself: no concatenation copy (20 ms per Llama-3-70B layer)
             items = [b.contiguous() for b in self._buf]

@@ -9,6 +9,11 @@ codes never leave HBM (`nncf_amd_gptq_pack8`: one 32-bit transpose), and its for
 `nncf_amd_gptq_dequant8`.  Parity of the LAYOUT with gptqmodel is unpinned (nothing in the reference holds packed
 tensors); what the reference's own test checks -- the converted layer computes the same linear
 (tests/integration/gptq_model/test_converter.py:25-57) -- is what the tests here check, bit-exactly.
+
+Symmetric layers, a DELIBERATE and unpinned choice: INT8_SYM codes are stored as code + 128 with qzeros = 128 (the
+GPTQ convention for signed codes in unsigned words), where the reference's convertor hands `pack` a zero point of 0.
+The forward is numerically the decompressor's linear either way, but the stored qweight / qzeros words of a symmetric
+layer must not be assumed interchangeable with a file gptqmodel wrote from the reference's convertor.
 """
 from typing import Union
 

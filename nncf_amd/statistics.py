@@ -41,6 +41,19 @@ def activation_stats(x: torch.Tensor, want_mean: bool = True, want_stats: bool =
     return mean, stats
 
 
+REDUCER_MAX_BATCH = 65535  # grid limit of the statistics kernel (leading axes folded into the batch)
+_REDUCER_DTYPES = (torch.float32, torch.float16, torch.bfloat16, torch.float64)
+
+
+def _check_reducer_input(t: torch.Tensor, who: str, batch: int) -> None:
+    """Inputs the HIP reducer does not take are UNSUPPORTED (the caller, e.g. install()'s patched reducers, takes the
+    reference's path for them), not faults of this library: other dtypes, more folded batch entries than the grid holds."""
+    if t.dtype not in _REDUCER_DTYPES:
+        raise UnsupportedModelError(f"nncf_amd {who}: activation dtype {t.dtype} is not one of fp32 / fp16 / bf16 / fp64")
+    if batch > REDUCER_MAX_BATCH:
+        raise UnsupportedModelError(f"nncf_amd {who}: {batch} leading entries exceed the kernel's limit of {REDUCER_MAX_BATCH}")
+
+
 def _norm_axes(ndim: int, axes) -> Tuple[int, ...]:
     if axes is None:
         return tuple(range(ndim))
@@ -86,6 +99,7 @@ class MeanReducer(_ReducerBase):
         if axes != tuple(range(t.ndim - 1)):
             msg = f"nncf_amd MeanReducer reduces all axes but the last; got axes={self._axes} for ndim={t.ndim}"
             raise UnsupportedModelError(msg)
+        _check_reducer_input(t, "MeanReducer", 1)
         mean, _ = activation_stats(t.reshape(1, -1, t.shape[-1]), want_stats=False)
         shape = [1] * (t.ndim - 1) + [t.shape[-1]]
         # torch.mean accumulates bf16/f16 in fp32 and rounds once to the input dtype
@@ -101,6 +115,7 @@ class _TokenStatReducer(_ReducerBase):
         if t.ndim < 2 or axes != (t.ndim - 2,):
             msg = f"nncf_amd {type(self).__name__} reduces axis -2; got axes={self._axes} for ndim={t.ndim}"
             raise UnsupportedModelError(msg)
+        _check_reducer_input(t, type(self).__name__, math.prod(t.shape[:-2]))
         _, stats = activation_stats(t, want_mean=False)
         return [stats[self._index].to(t.dtype)]
 
