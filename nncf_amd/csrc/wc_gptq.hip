@@ -13,22 +13,26 @@
 // this block's in-block updates, gptq.py:315-333) with the same policy arithmetic as the lowering kernels, the
 // column is quantize-dequantized with the IEEE divide, err = (w - q) / d, and every update is
 // w = w - fl(err * h) (separately rounded product and difference, as matmul of a [N,1] by a [1,M] gives).
+#include <stdlib.h>
+
 #include "wc_float_policy.h"
 #include "wc_int_policy.h"
 
 namespace wc {
 
 constexpr int GB = 128;   // max columns per call
-constexpr int GLPR = 16;  // lanes per row
-constexpr int GRPB = 32;  // rows per workgroup
-constexpr int GTHR = GRPB * GLPR;  // 512 threads: two workgroups (64 KiB of LDS each) put 4 waves on every SIMD
-constexpr int GCPL = GB / GLPR;  // columns per lane
+constexpr int GTHR = 256;  // threads per workgroup (64 KiB of LDS each: two workgroups per CU)
 
-template <typename Policy>
+// GLPR lanes own one row (GB / GLPR columns each).  Every lane of a row repeats the column's quantization, so the issue
+// slots per row and column are GLPR x (quantization + its share of the updates): 16 lanes per row spend ~850, 4 lanes
+// per row ~310; the launcher picks by the row count.
+template <typename Policy, int GLPR>
 __global__ __launch_bounds__(GTHR) void k_gptq_block(const float* __restrict__ weight, float* __restrict__ quantized,
                                                     float* __restrict__ err_block, const float* __restrict__ hinv,
                                                     int64_t rows, int64_t K, int64_t i1, int count, int64_t gs, int mode,
                                                     float* scales, int32_t* zps, int given) {
+    constexpr int GRPB = GTHR / GLPR;  // rows per workgroup
+    constexpr int GCPL = GB / GLPR;    // columns per lane
     extern __shared__ float hb[];  // [GB][GB]: Hinv[i1 + i][i1 + j], zero outside the block
     __shared__ float lds[kPolicyLds];
     Policy::init_shared(lds);
@@ -159,26 +163,46 @@ extern "C" int nncf_amd_gptq_block(const float* weight, float* quantized, float*
     }
     if (!asym) zps = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((rows + GRPB - 1) / GRPB));
     constexpr size_t hb_bytes = (size_t)GB * GB * sizeof(float);  // 64 KiB of dynamic LDS
+    // Few rows: the per-column dependent chain sets the time and 16 lanes per row keep it shortest (52 us per block at
+    // 8192 rows against 66 us with 4 lanes).  Many rows: the launch is bound by issue slots, which 4 lanes per row
+    // need 2.7x fewer of (28672 rows: 174 -> 84 us per block; 8 lanes: 123).  NNCF_AMD_GPTQ_LANES overrides (developer knob).
+    static const int forced_lanes = [] {
+        const char* e = getenv("NNCF_AMD_GPTQ_LANES");
+        const int v = e ? atoi(e) : 0;
+        return (v == 4 || v == 8 || v == 16) ? v : 0;
+    }();
+    const int lanes_per_row = forced_lanes ? forced_lanes : (rows >= 16384 ? 4 : 16);
+    auto launch = [&](auto kernel, int glpr) {
+        const int rpb = GTHR / glpr;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(GTHR), hb_bytes, s, weight, quantized,
+                           err_block, hinv, rows, k, i1, (int)count, gs, mode, scales, zps, use_given_params);
+    };
     static OncePerDevice attr_once;
     if (attr_once.first_on_device() != 0) {
-        if (hipFuncSetAttribute((const void*)k_gptq_block<IntPolicy>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_gptq_block<FloatPolicy<true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_gptq_block<FloatPolicy<false>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) != hipSuccess) {
+        bool ok = true;
+        auto opt_in = [&](auto kernel) {
+            ok = ok && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_bytes) == hipSuccess;
+        };
+        opt_in(k_gptq_block<IntPolicy, 4>), opt_in(k_gptq_block<IntPolicy, 8>), opt_in(k_gptq_block<IntPolicy, 16>);
+        opt_in(k_gptq_block<FloatPolicy<true>, 4>), opt_in(k_gptq_block<FloatPolicy<true>, 8>), opt_in(k_gptq_block<FloatPolicy<true>, 16>);
+        opt_in(k_gptq_block<FloatPolicy<false>, 4>), opt_in(k_gptq_block<FloatPolicy<false>, 8>), opt_in(k_gptq_block<FloatPolicy<false>, 16>);
+        if (!ok) {
             attr_once.forget_current();
             return launch_status("gptq_block attribute");
         }
     }
+    auto by_lanes = [&](auto k4, auto k8, auto k16) {
+        if (lanes_per_row == 4) launch(k4, 4);
+        else if (lanes_per_row == 8) launch(k8, 8);
+        else launch(k16, 16);
+    };
     if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
-        hipLaunchKernelGGL((k_gptq_block<IntPolicy>), grid, dim3(GTHR), hb_bytes, s, weight, quantized, err_block, hinv, rows, k, i1,
-                           (int)count, gs, mode, scales, zps, use_given_params);
+        by_lanes(k_gptq_block<IntPolicy, 4>, k_gptq_block<IntPolicy, 8>, k_gptq_block<IntPolicy, 16>);
     } else if (mode == NNCF_AMD_NF4) {
-        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<true>>), grid, dim3(GTHR), hb_bytes, s, weight, quantized, err_block, hinv, rows,
-                           k, i1, (int)count, gs, mode, scales, zps, use_given_params);
+        by_lanes(k_gptq_block<FloatPolicy<true>, 4>, k_gptq_block<FloatPolicy<true>, 8>, k_gptq_block<FloatPolicy<true>, 16>);
     } else if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) {
-        hipLaunchKernelGGL((k_gptq_block<FloatPolicy<false>>), grid, dim3(GTHR), hb_bytes, s, weight, quantized, err_block, hinv, rows,
-                           k, i1, (int)count, gs, mode, scales, zps, use_given_params);
+        by_lanes(k_gptq_block<FloatPolicy<false>, 4>, k_gptq_block<FloatPolicy<false>, 8>, k_gptq_block<FloatPolicy<false>, 16>);
     } else {
         set_error("gptq_block: unsupported mode %d", mode);
         return NNCF_AMD_ERR_MODE;

@@ -155,7 +155,7 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
     N, K = W.shape
     if hinv is None:
         hinv, dead = prepare_hinv(hessian, damp_percent)
-    W[:, dead] = 0
+    W.masked_fill_(dead.unsqueeze(0), 0.0)  # W[:, dead] = 0 (gptq.py:271) without the host round trip of a mask index
     gs = config.group_size if config.group_size != -1 else K
     ngroups = K // gs
 
@@ -251,31 +251,74 @@ def quantize_node_weight(weight: torch.Tensor, inputs: List[torch.Tensor], confi
 
 
 def quantize_units(units, config: WeightCompressionConfig, damp_percent: float = 0.1, block_size: int = 128,
-                   overlap: bool = False, on_weight=None):
+                   overlap: str = "units", on_weight=None):
     """GPTQ over a sequence of independent units (gptq.py:118-171 for nodes that come with their own activations: the
     Linears reading one activation share ONE Hessian and ONE Hinv).  `units` yields (inputs, {name: weight [N, K]});
     returns {name: (quantized fp32 [N, K], scale, zero_point | None)} -- or whatever `on_weight(name, weight, q, scale,
     zp)` returns for each weight (e.g. the packed codes, so that the fp32 result does not stay alive).
 
-    overlap: two HIP streams -- the Hessian of unit i + 1 (MFMA-bound, fills the chip) is issued on its own stream
-    BEFORE the host starts on unit i's Hinv and column sweeps, whose chains of small dependent kernels leave most of
-    the chip idle.  Same arithmetic (same kernels, same order within a stream).  MEASURED on one Llama-3-70B layer
-    (tools/bench_configs.py c4, A/B/A/B): 612 / 606 / 611 / 608 ms -- the SYRK's one-wave-per-SIMD blocks leave the
-    second queue no room on a CU until they retire, so the chains stretch by what the overlap saves; off by default."""
+    overlap (same kernels and the same order within a unit in every mode; only what may run side by side changes):
+      "none"     one stream, unit after unit.
+      "units"    all Hessians first (MFMA-bound, each fills the chip), then every unit's Hinv + column sweeps on a HIP
+                 stream of its own: those are long chains of small dependent kernels (128-column base blocks, small
+                 GEMMs of the recursion's lower levels, in-block sweeps) that leave most of the chip idle, so the
+                 chains of different units interleave.  Nothing in a chain waits for the host (the Cholesky failure
+                 flags are read once at the end).  Holds every unit's Hessian / Hinv at once.
+      "hessian"  the Hessian of unit i + 1 on a second stream under unit i's chains.  Measured on a Llama-3-70B layer
+                 (tools/bench_configs.py c4): 612 -> 606 ms, the SYRK's one-wave-per-SIMD blocks leave a second queue
+                 no room on a CU until they retire; kept for memory-tight callers."""
     config = as_config(config)
+    if overlap not in ("none", "units", "hessian"):
+        raise ValueError(f"quantize_units: overlap must be 'none', 'units' or 'hessian', got {overlap!r}")
     out = {}
+
+    def sweeps(weights, hinv, dead):
+        for name, w in weights.items():
+            w32 = w.to(torch.float32).contiguous()
+            if w32 is w or w32.data_ptr() == w.data_ptr():
+                w32 = w32.clone()  # quantize_weights works in place
+            q, scale, zp = quantize_weights(None, w32, config, hinv=hinv, dead=dead, damp_percent=damp_percent,
+                                            block_size=block_size)
+            out[name] = on_weight(name, w, q, scale, zp) if on_weight is not None else (q, scale, zp)
+
+    if overlap == "units":
+        pending = [(calculate_hessian(inputs)[0], weights) for inputs, weights in units]
+        if not pending:
+            return out
+        dev = pending[0][0].device
+        main = torch.cuda.current_stream(dev)
+        infos = torch.zeros((len(pending), 1), dtype=torch.int32, device=dev)
+        streams = [torch.cuda.Stream(dev) for _ in pending]
+        # the longest chain first: its tail is what the others have to fit under
+        order = sorted(range(len(pending)), key=lambda i: -pending[i][0].shape[0])
+        for i in order:
+            hessian, weights = pending[i]
+            streams[i].wait_stream(main)
+            with torch.cuda.stream(streams[i]):
+                hinv, dead = prepare_hinv(hessian, damp_percent, info=infos[i])
+                sweeps(weights, hinv, dead)
+                del hinv
+            hessian.record_stream(streams[i])
+        for st in streams:
+            main.wait_stream(st)
+        check_hinv_info(infos)
+        for v in out.values():  # results were allocated on the side streams: hand them to the caller's stream
+            for t in (v if isinstance(v, (tuple, list)) else (v,)):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
+        return out
+
     it = iter(units)
-    dev = None
-    side = main = None
+    dev = side = main = None
 
     def start_hessian(unit):
         nonlocal dev, side, main
         inputs, weights = unit
         if dev is None:
             dev = inputs[0].device
-            if overlap:
+            if overlap == "hessian":
                 main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
-        if not overlap:
+        if overlap != "hessian":
             return calculate_hessian(inputs)[0], None, weights
         side.wait_stream(main)  # the inputs were produced on the caller's stream
         with torch.cuda.stream(side):
@@ -295,11 +338,7 @@ def quantize_units(units, config: WeightCompressionConfig, damp_percent: float =
             hessian.record_stream(main)
         hinv, dead = prepare_hinv(hessian, damp_percent)
         del hessian
-        for name, w in weights.items():
-            q, scale, zp = quantize_weights(None, w.to(torch.float32).contiguous().clone() if w.dtype == torch.float32
-                                            else w.to(torch.float32).contiguous(), config, hinv=hinv, dead=dead,
-                                            damp_percent=damp_percent, block_size=block_size)
-            out[name] = on_weight(name, w, q, scale, zp) if on_weight is not None else (q, scale, zp)
+        sweeps(weights, hinv, dead)
         del hinv
     if side is not None:
         main.wait_stream(side)
@@ -424,36 +463,47 @@ def _cholinv_lower(A: torch.Tensor, Linv: torch.Tensor, info: torch.Tensor) -> N
     Linv[h:, :h].neg_()
 
 
-def _upper_cholesky_of_inverse(hessian: torch.Tensor) -> torch.Tensor:
+_NOT_SPD = "linalg.cholesky: The factorization could not be completed because the input is not positive-definite"
+
+
+def _upper_cholesky_of_inverse(hessian: torch.Tensor, info: Optional[torch.Tensor] = None) -> torch.Tensor:
     """U upper triangular with H^-1 = U^T U: what the reference gets from cholesky -> cholesky_inverse ->
     cholesky(upper=True) (gptq.py:283-285), from ONE factorization instead of two plus an inversion.  With J the
     index reversal, J H J = L L^T (plain Cholesky) gives H = R R^T for the upper triangular R = J L J, hence
     H^-1 = R^-T R^-1 = U^T U with U = R^-1 = J L^-1 J, and a Cholesky factor with positive diagonal is unique.  In
     fp32 this is at least as close to the exact U as the three-step chain (one rounding cascade less).  L^-1 comes
-    from the GEMM-based recursion `_cholinv_lower`."""
+    from the GEMM-based recursion `_cholinv_lower`.
+    `info` (int32 [1] on the device, zeroed by the caller): the failure flag is left there and NOT read, so that the
+    call stays asynchronous (several factorizations in flight on different streams); the caller checks it once with
+    `check_hinv_info`.  Without it the call synchronises and raises like the reference's cholesky."""
     A = torch.flip(hessian, (0, 1)).contiguous()
     Linv = torch.zeros_like(A)
-    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    own = info is None
+    if own:
+        info = torch.zeros(1, dtype=torch.int32, device=A.device)
     _cholinv_lower(A, Linv, info)
     U = torch.flip(Linv, (0, 1)).contiguous()
-    if int(info.item()) != 0:  # one synchronisation per factorization; same failure the reference's cholesky raises
-        msg = "linalg.cholesky: The factorization could not be completed because the input is not positive-definite"
-        raise torch.linalg.LinAlgError(msg)
+    if own:
+        check_hinv_info(info)  # one synchronisation per factorization; same failure the reference's cholesky raises
     return U
 
 
-def prepare_hinv(hessian: torch.Tensor, damp_percent: float = 0.1):
+def check_hinv_info(info: torch.Tensor) -> None:
+    if int(info.max().item()) != 0:
+        raise torch.linalg.LinAlgError(_NOT_SPD)
+
+
+def prepare_hinv(hessian: torch.Tensor, damp_percent: float = 0.1, info: Optional[torch.Tensor] = None):
     """gptq.py:269-295 up to `hessian_inv`: dead columns, damping, U = chol_upper(H^-1).  `hessian` [K, K] fp32 is
     modified in place like the reference does.  Returns (U, dead-column mask); Linears that read one activation
-    share both."""
+    share both.  Nothing here waits for the device when `info` is given (see `_upper_cholesky_of_inverse`)."""
     assert hessian.ndim == 2 and hessian.dtype == torch.float32, "Hessian should be 2D fp32"
-    K = hessian.shape[0]
-    dead = torch.diag(hessian) == 0
-    idx = torch.arange(K, device=hessian.device)
-    hessian[idx[dead], idx[dead]] = 1
-    damp = damp_percent * torch.mean(torch.diag(hessian))
-    hessian[idx, idx] += damp
-    return _upper_cholesky_of_inverse(hessian), dead
+    diag = hessian.diagonal()
+    dead = diag == 0
+    fixed = torch.where(dead, torch.ones((), dtype=diag.dtype, device=diag.device), diag)  # H[dead, dead] = 1  (:270)
+    damp = damp_percent * torch.mean(fixed)
+    diag.copy_(fixed + damp)
+    return _upper_cholesky_of_inverse(hessian, info), dead
 
 
 class GPTQ:

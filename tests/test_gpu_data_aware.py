@@ -225,6 +225,82 @@ def test_gptq_straddling_group_sees_pending_errors():
     np.testing.assert_allclose(host(s), s_ref, rtol=2e-5)
 
 
+@pytest.mark.parametrize("mode,gs", [("int4_sym", 64), ("int4_asym", 32), ("nf4", 64), ("mxfp4", 32)])
+def test_gptq_sweep_many_rows_four_lanes_per_row(mode, gs):
+    """From 16384 rows on the launcher takes the 4-lanes-per-row form of the sweep kernel (32 columns per lane); same
+    check as for the 16-lane form: gptq.quantize_weights against the oracle's column loop with the SAME factor U on a
+    slice of the rows (rows are independent), first block bit-exact, the ragged last workgroup included."""
+    from nncf_amd import gptq
+    N, K = 16384 + 37, 320
+    W, U = _same_hinv_case(N, K, seed=11)
+    Q, sc, zp = gptq.quantize_weights(None, W.clone(), _cfg(mode, gs), hinv=U,
+                                      dead=torch.zeros(K, dtype=torch.bool, device="cuda"))
+    for rows in (slice(0, 24), slice(N - 50, N)):
+        q_ref, s_ref, z_ref = O.gptq_quantize_weights(None, host(W[rows]).copy(), mode, gs, hinv=host(U))
+        assert np.array_equal(host(Q[rows])[:, :128], q_ref[:, :128])
+        assert np.isclose(host(Q[rows]), q_ref, rtol=1e-4, atol=1e-7).mean() >= 0.995
+        assert np.isclose(host(sc[rows]), s_ref, rtol=2e-5, atol=0).mean() >= 0.995
+        if z_ref is not None:
+            assert (host(zp[rows]) == z_ref).mean() >= 0.995
+
+
+def test_quantize_units_stream_modes_agree():
+    """gptq.quantize_units: the units of a layer on one stream, with every unit's Hinv + sweeps on a stream of its own
+    (all Hessians first), and with the next Hessian on a second stream -- the same kernels in the same order within a
+    unit; a Hessian that is not positive definite raises the reference's error
+    in the asynchronous mode too (its flag is read once, at the end)."""
+    from nncf_amd import gptq
+    g = torch.Generator(device="cuda").manual_seed(4)
+    cfg = _cfg("int4_asym", 32)
+
+    def make_units():
+        units = []
+        for u, (k, outs) in enumerate(((256, (40, 24)), (384, (64,)), (1280, (48, 16, 16)))):
+            xs = [torch.randn(1, 300 + 20 * i, k, device="cuda", generator=g).to(torch.bfloat16) for i in range(4)]
+            ws = {f"u{u}.w{j}": (torch.randn(n, k, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+                  for j, n in enumerate(outs)}
+            units.append((xs, ws))
+        return units
+
+    units = make_units()
+    ref = gptq.quantize_units(units, cfg, overlap="none")
+    assert sorted(ref) == sorted(n for _, ws in units for n in ws)
+    for mode in ("units", "hessian"):
+        got = gptq.quantize_units(units, cfg, overlap=mode)
+        torch.cuda.synchronize()
+        assert sorted(got) == sorted(ref)
+        # (the SYRK adds its token splits with fp32 atomics, so a Hessian is reproducible to rounding only and GPTQ
+        # turns a last-bit difference into a few different codes: the reference's own bar for two GPTQ runs,
+        # tests/openvino/native/quantization/test_gptq.py:421-452)
+        for name in ref:
+            for a, b in zip(got[name], ref[name]):
+                assert a.shape == b.shape and a.dtype == b.dtype
+                assert float(torch.isclose(a.float(), b.float(), rtol=1e-4, atol=1e-7).float().mean()) >= 0.97, (mode, name)
+    packed = gptq.quantize_units(units, cfg, overlap="units", on_weight=lambda name, w, q, sc, zp: (q != 0).sum())
+    assert all(int(v) > 0 for v in packed.values())
+    # weights are not modified, and the single-unit API gives the same result as the pipeline
+    xs, ws = units[1]
+    before = ws["u1.w0"].clone()
+    q, sc, zp = gptq.quantize_node_weight(ws["u1.w0"], xs, cfg)
+    assert torch.equal(ws["u1.w0"], before)
+    assert float(torch.isclose(q, ref["u1.w0"][0], rtol=1e-4, atol=1e-7).float().mean()) >= 0.97
+    assert tuple(sc.shape) == tuple(ref["u1.w0"][1].shape) and tuple(zp.shape) == tuple(ref["u1.w0"][2].shape)
+    # dead columns (all-zero channels) go through the sync-free dead-column fix
+    xd = [torch.randn(1, 200, 128, device="cuda", generator=g) for _ in range(2)]
+    for x in xd:
+        x[..., 5] = 0.0
+    wd = torch.randn(8, 128, device="cuda", generator=g) * 0.05
+    qd = gptq.quantize_units([(xd, {"d": wd})], cfg, overlap="units")["d"][0]
+    assert bool((qd[:, 5] == 0).all()) and bool(torch.isfinite(qd).all())
+    # a Hessian the factorization cannot take (NaN activations): the reference's error, also from the asynchronous mode
+    xn = [torch.full((1, 64, 128), float("nan"), device="cuda")]
+    for mode in ("none", "units"):
+        with pytest.raises(torch.linalg.LinAlgError):
+            gptq.quantize_units([(units[0][0], units[0][1]), (xn, {"n": wd})], cfg, overlap=mode)
+    with pytest.raises(ValueError):
+        gptq.quantize_units(units, cfg, overlap="all")
+
+
 def _se_case(shape, n_samples, seed, device="cuda"):
     """Weight + per-sample token means with outlier channels (what WCTensorStatistic carries)."""
     from nncf_amd.statistics import WCTensorStatistic

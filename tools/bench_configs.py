@@ -129,7 +129,8 @@ def c4(args):
         def pack(name, w, q, sc, zp):
             return wl.compress_weight_packed(q.to(torch.bfloat16), (1,), cfg, CompressedWeight(None, sc, zp)).tensor
 
-        for mode, ov in (("sequential", False), ("two_streams", True), ("sequential_again", False), ("two_streams_again", True)):
+        for mode, ov in (("sequential", "none"), ("unit_streams", "units"), ("next_hessian_stream", "hessian"),
+                         ("sequential_again", "none"), ("unit_streams_again", "units")):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             res = gptq.quantize_units(units(), cfg, overlap=ov, on_weight=pack)
