@@ -176,16 +176,19 @@ def all_gather_sample_statistics(local: Sequence[torch.Tensor], n_samples: int, 
 # Units are independent given their activations, so they are spread by LPT on an operation count and every rank
 # loads / streams only the activations of the units it owns.  Nothing is reduced across ranks (Hessians stay on their
 # owner); the only exchange is the final all-gather of packed codes + scales (+ zero points).
-def run_sharded(costs: Sequence[float], work_fn, gather: bool = True, group=None) -> Dict:
+def run_sharded(costs: Sequence[float], work_fn, gather: bool = True, group=None, chunk: int = 1) -> Dict:
     """costs[i] = relative cost of unit i (same list on every rank); work_fn(i) -> {key: tuple of tensors / None}
-    is called on the owner of unit i only.  Returns the union of all ranks' dictionaries (gather=True) or this
-    rank's own.  Keys must be unique across units and picklable; one all_gather_object of metadata (keys, shapes,
-    dtypes) + ONE all_gather_into_tensor of the padded flat payload."""
+    is called on the owner of unit i only (chunk > 1: work_fn(list of up to `chunk` owned units), for work that runs
+    several units side by side).  Returns the union of all ranks' dictionaries (gather=True) or this rank's own.
+    Keys must be unique across units and picklable; one all_gather_object of metadata (keys, shapes, dtypes) + ONE
+    all_gather_into_tensor of the padded flat payload."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     scale = max([float(c) for c in costs] + [1.0])
     parts = partition_lpt([int(float(c) / scale * (1 << 40)) + 1 for c in costs], world)
     local: Dict = {}
-    for i in parts[rank]:
+    mine = sorted(parts[rank])  # unit order: neighbouring units (a layer's) share a chunk
+    calls = [mine[c:c + chunk] for c in range(0, len(mine), chunk)] if chunk > 1 else mine
+    for i in calls:
         for key, val in work_fn(i).items():
             if key in local:
                 raise ValueError(f"run_sharded: key {key!r} returned twice")
@@ -218,16 +221,36 @@ def gptq_unit_cost(k: int, tokens: int, out_features: Sequence[int]) -> float:
 
 
 def gptq_sharded(units, config, load_unit, gather: bool = True, group=None, damp_percent: float = 0.1,
-                 block_size: int = 128, backend=None) -> Dict:
+                 block_size: int = 128, backend=None, concurrent_units: int = 4) -> Dict:
     """GPTQ over a list of units, layer-sharded (gptq.py:82-171 without the cross-layer replay: every unit comes with
     its own activations, as in BASELINE configs[3]'s synthetic calibration set).
       units[i] = {"k": K, "tokens": T, "weights": [(name, out_features), ...]}   -- the same list on every rank
       load_unit(i) -> (activations: list of [.., T_j, K] tensors, weights: {name: [N, K] tensor}) on the owner only
     Returns {name: (packed codes uint8, scale fp32, zero point int32 | None)}.
-    `backend` (test hook) supplies calculate_hessian / prepare_hinv / quantize_weights / pack."""
+    `backend` (test hook) supplies calculate_hessian / prepare_hinv / quantize_weights / pack.
+    concurrent_units: a rank takes its units in chunks of this many (a decoder layer has four) through
+    gptq.quantize_units(overlap="units"): all Hessians of the chunk, then every unit's Hinv + column sweeps on a HIP
+    stream of its own (a chunk's activations, Hessians and Hinvs are resident together)."""
     from nncf_amd.parameters import CompressedWeight, as_config
 
     config = as_config(config)
+    costs = [gptq_unit_cost(u["k"], u["tokens"], [n for _, n in u["weights"]]) for u in units]
+    if backend is None and concurrent_units > 1:
+        from nncf_amd import gptq as _gptq, weight_lowering as _wl
+
+        def work_chunk(indices):
+            def loaded():
+                for i in indices:
+                    xs, ws = load_unit(i)
+                    yield xs, {name: ws[name] for name, _ in units[i]["weights"]}
+
+            def pack(name, w, q, scale, zp):
+                cw = _wl.compress_weight_packed(q.to(w.dtype), (1,), config, CompressedWeight(None, scale, zp))
+                return cw.tensor, scale, zp
+
+            return _gptq.quantize_units(loaded(), config, damp_percent, block_size, overlap="units", on_weight=pack)
+
+        return run_sharded(costs, work_chunk, gather=gather, group=group, chunk=concurrent_units)
     if backend is None:
         from nncf_amd import gptq as _gptq, weight_lowering as _wl
 
@@ -244,8 +267,6 @@ def gptq_sharded(units, config, load_unit, gather: bool = True, group=None, damp
             def pack(q, scale, zp, dtype):
                 cw = _wl.compress_weight_packed(q.to(dtype), (1,), config, CompressedWeight(None, scale, zp))
                 return cw.tensor
-
-    costs = [gptq_unit_cost(u["k"], u["tokens"], [n for _, n in u["weights"]]) for u in units]
 
     def work(i):
         xs, ws = load_unit(i)
