@@ -264,6 +264,17 @@ int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t* zero_mask,
                      float zero_scale, float weight_penalty, void* stream);
 
 /*
+ * The whole search of scale_estimation.py:236-360 for one weight in one call: nncf_amd_se_zero_mask, then
+ * nncf_amd_se_step kind 0, `initial_steps` x kind 1, `scale_steps` x kind 2 with factor 1 - 0.05 k (:301), queued back
+ * to back on `stream`.  Same buffers as those two (zero_mask / rden are scratch the call fills itself).
+ */
+int nncf_amd_se_search(const void* weight, int w_dtype, uint32_t* zero_mask, float* rden, const float* s_per_channel,
+                       const float* x, float* fp_outs, const float* scale0, const float* zero_point, float* best_diffs,
+                       float* result_scale, int64_t batch, int64_t rows, int64_t groups, int64_t group_size,
+                       int64_t n_samples, int mode, int initial_steps, int scale_steps, float zero_scale,
+                       float weight_penalty, void* stream);
+
+/*
  * AWQ alpha-grid search (AWQ._data_aware_step, src/nncf/quantization/algorithms/weight_compression/awq.py:297-352):
  * for every outlier group g and every candidate scale vector s = 0..steps-1
  *     wq = gweight_g * scale[g, s];  dq = per-row quantize-dequantize(wq)  (one quantization group per row, :337-341)
@@ -278,6 +289,17 @@ int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t* zero_mask,
  *   fp_out: fp32 [groups, rows, n_samples] (:307);  partial: fp32 [groups, steps, ceil(rows / 16)].
  */
 int nncf_amd_awq_sacts_tiles(int64_t group_size, int64_t n_samples);
+/*
+ * Preparation of nncf_amd_awq_search for a set of outlier groups, one launch (awq.py:311-342): per group g and alpha
+ * step s the candidate scale vector cur = gscale[g] ^ alphas[s] (sqrt for 0.5), the fp16-overflow clamp of :315-335 when
+ * the previous matmul is merged (gprev = mean |previous weight| of the group's channels, prev_s = max activation
+ * magnitude in front of it, n_prev = its reduction length; gprev NULL: no clamp), and gacts / cur in the layout
+ * nncf_amd_awq_sacts_tiles names.  gscale: fp32 [groups, group_size], clipped to [quantile 0.1, 100] (:300-301);
+ * gacts: fp32 [groups, group_size, n_samples];  scales: fp32 [groups, steps, group_size];  sacts: see above.
+ */
+int nncf_amd_awq_prepare(const float* gscale, const float* alphas, const float* gacts, const float* gprev, float prev_s,
+                         float n_prev, int groups, int steps, int64_t group_size, int64_t n_samples, float* scales,
+                         float* sacts, void* stream);
 int nncf_amd_awq_search(const float* weight, int64_t rows, int64_t row_pitch, const int64_t* group_offsets, int groups,
                         int64_t group_size, const float* scales, int steps, const float* sacts, const float* fp_out,
                         int64_t n_samples, int mode, float* partial, void* stream);

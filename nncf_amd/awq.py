@@ -31,30 +31,13 @@ def _quantile_rows(x: torch.Tensor, q: float) -> torch.Tensor:
     return torch.lerp(srt[:, below:below + 1], srt[:, above:above + 1], weight)
 
 
-def _candidate_scales(gscale, alpha_min, alpha_step, steps, gprev, prev_s, n_prev):
-    """cur_scale of every alpha step, [..., steps, gs] for gscale [..., gs] (awq.py:311-335 incl. the fp16-overflow
-    clamp; gprev [..., gs] = mean |previous weight| of the group's channels)."""
-    alphas = []
-    alpha = alpha_min
+def _alphas(alpha_min: float, alpha_step: float, steps: int) -> np.ndarray:
+    """The alpha grid as the reference's loop produces it (awq.py:309, 347: a running Python float sum), in fp32."""
+    alphas, alpha = [], alpha_min
     for _ in range(steps):
         alphas.append(alpha)
         alpha += alpha_step
-    alphas32 = np.asarray(alphas, dtype=np.float64).astype(np.float32)
-    alphas_t = torch.from_numpy(alphas32).to(gscale.device)
-    all_scales = torch.pow(gscale.unsqueeze(-2), alphas_t.unsqueeze(-1))
-    half = np.nonzero(alphas32 == np.float32(0.5))[0]  # tensor ** python-scalar takes the sqrt path for exactly 0.5
-    if half.size:
-        root = torch.sqrt(gscale)
-        for j in half.tolist():
-            all_scales[..., j, :] = root
-    if prev_s is not None:
-        threshold = FP16_OVERFLOW_MARGIN * FP16_MAX_VALUE
-        # awq.py:321-335, same operation order: (prev_w / cur_scale) * prev_s * n  vs  prev_w * prev_s * n / threshold
-        magnitudes = (gprev.unsqueeze(-2) / all_scales) * prev_s * n_prev
-        clamped = gprev * prev_s * n_prev / threshold
-        clip_rows = magnitudes.amax(dim=-1, keepdim=True) >= threshold
-        all_scales = torch.where(clip_rows & ~(magnitudes < threshold), clamped.unsqueeze(-2), all_scales)
-    return all_scales
+    return np.asarray(alphas, dtype=np.float64).astype(np.float32)
 
 
 def _group_search(weight, s, X, config, group_size, groups, scale, alpha_min, alpha_step, steps, prev_s, prev_w, n_prev):
@@ -71,6 +54,7 @@ def _group_search(weight, s, X, config, group_size, groups, scale, alpha_min, al
     tiles = (N + 15) // 16
     mode_id = _lib.MODE_ID[config.mode.value]
     w4 = weight.view(B, N, G, group_size)
+    alphas_t = torch.from_numpy(_alphas(alpha_min, alpha_step, steps)).to(dev)
     for c0 in range(0, len(groups), GROUPS_PER_LAUNCH):
         chunk = groups[c0:c0 + GROUPS_PER_LAUNCH]
         nc = len(chunk)
@@ -83,14 +67,17 @@ def _group_search(weight, s, X, config, group_size, groups, scale, alpha_min, al
         gscale = torch.minimum(torch.maximum(gscale, a_min), torch.full_like(gscale, 1e2))
         fp_out = torch.matmul(gweight, gacts).contiguous()              # [nc, N, n]
         min_diff = fp_out.abs().amax(dim=(1, 2))
-        gprev = prev_w.reshape(B, G, group_size)[bi, gi] if prev_s is not None else None
-        all_scales = _candidate_scales(gscale, alpha_min, alpha_step, steps, gprev, prev_s, n_prev).contiguous()
-        sacts = gacts.unsqueeze(1) / all_scales.unsqueeze(3)            # [nc, steps, gs, n]  (awq.py:342)
-        if nt:
-            if n < 16 * nt:
-                sacts = torch.nn.functional.pad(sacts, (0, 16 * nt - n))
-            sacts = sacts.reshape(nc, steps, group_size, nt, 16).transpose(3, 4)  # kernel layout [.., 16, NT]
-        sacts = sacts.contiguous()
+        gprev = prev_w.reshape(B, G, group_size)[bi, gi].contiguous() if prev_s is not None else None
+        # candidate scales of every alpha step incl. the fp16-overflow clamp, and gacts / scale in the search kernel's
+        # layout (awq.py:311-342): one launch
+        all_scales = torch.empty((nc, steps, group_size), dtype=torch.float32, device=dev)
+        sacts = torch.empty((nc, steps, group_size, 16 * nt if nt else n), dtype=torch.float32, device=dev)
+        gscale, gacts = gscale.contiguous(), gacts.contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(lib.nncf_amd_awq_prepare(_lib.ptr(gscale), _lib.ptr(alphas_t), _lib.ptr(gacts), _lib.ptr(gprev),
+                                                float(prev_s) if prev_s is not None else 0.0, float(n_prev), nc, steps,
+                                                group_size, n, _lib.ptr(all_scales), _lib.ptr(sacts),
+                                                _lib.stream_of(weight)))
         goff = bi * (N * K) + gi * group_size
         partial = torch.empty((nc, steps, tiles), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):

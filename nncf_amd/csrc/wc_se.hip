@@ -1023,6 +1023,34 @@ extern "C" int nncf_amd_se_zero_mask(const void* weight, int w_dtype, const floa
     return NNCF_AMD_ERR_MODE;
 }
 
+// The whole search of one weight in ONE call: zero mask, baseline, `initial_steps` rectifications, `scale_steps` grid
+// candidates (factor 1 - 0.05 k, scale_estimation.py:301) -- the same launches nncf_amd_se_zero_mask / nncf_amd_se_step
+// make, queued back to back from here instead of one FFI round trip each (12 per weight with the reference's defaults).
+extern "C" int nncf_amd_se_search(const void* weight, int w_dtype, uint32_t* zero_mask, float* rden,
+                                  const float* s_per_channel, const float* x, float* fp_outs, const float* scale0,
+                                  const float* zero_point, float* best_diffs, float* result_scale, int64_t batch,
+                                  int64_t rows, int64_t groups, int64_t group_size, int64_t n_samples, int mode,
+                                  int initial_steps, int scale_steps, float zero_scale, float weight_penalty, void* stream) {
+    if (initial_steps < 0 || scale_steps < 0) {
+        wc::set_error("se_search: negative step count");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    int st = nncf_amd_se_zero_mask(weight, w_dtype, s_per_channel, scale0, zero_point, batch, rows, groups, group_size, mode,
+                                   zero_mask, rden, stream);
+    if (st != NNCF_AMD_OK) return st;
+    auto step = [&](int kind, float factor) {
+        return nncf_amd_se_step(weight, w_dtype, zero_mask, rden, s_per_channel, x, fp_outs, scale0, zero_point, best_diffs,
+                                result_scale, batch, rows, groups, group_size, n_samples, mode, kind, factor, zero_scale,
+                                weight_penalty, stream);
+    };
+    if ((st = step(0, 1.0f)) != NNCF_AMD_OK) return st;
+    for (int i = 0; i < initial_steps; ++i)
+        if ((st = step(1, 1.0f)) != NNCF_AMD_OK) return st;
+    for (int k = 0; k < scale_steps; ++k)
+        if ((st = step(2, (float)(1.0 - 0.05 * k))) != NNCF_AMD_OK) return st;
+    return NNCF_AMD_OK;
+}
+
 // ====================================================================================================================
 // AWQ alpha-grid search (awq.py:297-352), every outlier group and every alpha step in ONE launch.  The reference walks
 // the groups and, per group, 100 candidate scales cur = clip(s_g)^alpha; per candidate:
@@ -1169,6 +1197,99 @@ __global__ __launch_bounds__(256) void k_awq_search(AwqArgs a) {
         if (lane == 0) a.partial[((int64_t)g * a.steps + s) * tiles + tile] = sum;
     }
 }
+
+// Preparation of the search for a set of outlier groups (awq.py:311-342), one launch: the candidate scale vector of every
+// alpha step, cur = gscale^alpha (sqrt for alpha == 0.5, as `tensor ** 0.5` evaluates), the fp16-overflow clamp when the
+// previous matmul absorbs 1 / scale (:315-335: where the scaled previous weight would leave a quarter of the fp16 range,
+// those channels take prev_w * prev_s * n / threshold), and the scaled activations gacts / cur in the layout the search
+// kernel reads.  Replaces ~15 small torch kernels and two 46 MB temporaries per 28 groups of a Llama down_proj.
+struct AwqPrepArgs {
+    const float* gscale;  // [groups, gs], already clipped to [quantile 0.1, 100]
+    const float* alphas;  // [steps]
+    const float* gacts;   // [groups, gs, ns]
+    const float* gprev;   // [groups, gs] mean |previous weight| per channel, or NULL (no merged matmul)
+    float* scales;        // [groups, steps, gs]
+    float* sacts;         // tiles > 0: [groups, steps, gs, 16, tiles]; tiles == 0: [groups, steps, gs, ns]
+    int gs, ns, steps, tiles;
+    float prev_s, n_prev;
+};
+
+__global__ __launch_bounds__(256) void k_awq_prepare(AwqPrepArgs a) {
+    extern __shared__ float cur[];  // [gs]
+    __shared__ float red[4];
+    const int s = blockIdx.x, g = blockIdx.y, gs = a.gs, ns = a.ns;
+    const float alpha = a.alphas[s];
+    const float threshold = 0.25f * 65504.0f;
+    float worst = 0.0f;
+    for (int k = threadIdx.x; k < gs; k += 256) {
+        const float x = a.gscale[(int64_t)g * gs + k];
+        const float c = alpha == 0.5f ? sqrtf(x) : powf(x, alpha);
+        cur[k] = c;
+        if (a.gprev) worst = fmaxf(worst, ((a.gprev[(int64_t)g * gs + k] / c) * a.prev_s) * a.n_prev);
+    }
+    if (a.gprev) {  // uniform
+        worst = block_allreduce<4>(worst, OpMax(), red);
+        const bool clip_row = worst >= threshold;
+        __syncthreads();
+        for (int k = threadIdx.x; k < gs; k += 256) {
+            const float pw = a.gprev[(int64_t)g * gs + k];
+            const float mag = ((pw / cur[k]) * a.prev_s) * a.n_prev;
+            if (clip_row && !(mag < threshold)) cur[k] = ((pw * a.prev_s) * a.n_prev) / threshold;
+        }
+    }
+    __syncthreads();
+    float* so = a.scales + ((int64_t)g * a.steps + s) * gs;
+    for (int k = threadIdx.x; k < gs; k += 256) so[k] = cur[k];
+    const float* ga = a.gacts + (int64_t)g * gs * ns;
+    if (a.tiles > 0) {
+        const int width = 16 * a.tiles;  // per k: [16 columns][tiles], sample t*16 + c at c * tiles + t
+        float* out = a.sacts + ((int64_t)g * a.steps + s) * gs * width;
+        for (int idx = threadIdx.x; idx < gs * width; idx += 256) {
+            const int k = idx / width, r = idx % width, c = r / a.tiles, t = r % a.tiles, j = t * 16 + c;
+            out[idx] = j < ns ? ga[k * ns + j] / cur[k] : 0.0f;
+        }
+    } else {
+        float* out = a.sacts + ((int64_t)g * a.steps + s) * gs * ns;
+        for (int64_t idx = threadIdx.x; idx < (int64_t)gs * ns; idx += 256) out[idx] = ga[idx] / cur[idx / ns];
+    }
+}
+
+}  // namespace wc
+
+extern "C" int nncf_amd_awq_sacts_tiles(int64_t group_size, int64_t n_samples);
+
+extern "C" int nncf_amd_awq_prepare(const float* gscale, const float* alphas, const float* gacts, const float* gprev,
+                                    float prev_s, float n_prev, int groups, int steps, int64_t group_size,
+                                    int64_t n_samples, float* scales, float* sacts, void* stream) {
+    using namespace wc;
+    if (groups < 0 || steps < 0 || group_size < 1 || n_samples < 1 || n_samples > 0x7fffffff / group_size) {
+        set_error("awq_prepare: bad argument");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (group_size > 40000) {  // one group's candidate scale sits in LDS (160 KB)
+        set_error("awq_prepare: group size %lld exceeds 40000", (long long)group_size);
+        return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+    if (groups == 0 || steps == 0) return NNCF_AMD_OK;
+    if (!gscale || !alphas || !gacts || !scales || !sacts || groups > 65535) {
+        set_error("awq_prepare: NULL buffer or more than 65535 groups");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    AwqPrepArgs a = {gscale, alphas, gacts, gprev, scales, sacts, (int)group_size, (int)n_samples, steps,
+                     nncf_amd_awq_sacts_tiles(group_size, n_samples), prev_s, n_prev};
+    static OncePerDevice attr_once;
+    if (attr_once.first_on_device() != 0) {
+        if (hipFuncSetAttribute((const void*)k_awq_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, 160000) != hipSuccess) {
+            attr_once.forget_current();
+            return launch_status("awq_prepare attribute");
+        }
+    }
+    hipLaunchKernelGGL(k_awq_prepare, dim3((unsigned)steps, (unsigned)groups), dim3(256), (size_t)group_size * sizeof(float),
+                       (hipStream_t)stream, a);
+    return launch_status("awq_prepare");
+}
+
+namespace wc {
 
 // Any group size / sample count: a wave owns a 16-row tile (four sets of R = 4 rows, so `partial` keeps the tiled
 // kernel's [groups, steps, ceil(rows / 16)] shape) of one group for a run of alpha steps.  Per step and row set: pass 1

@@ -1,6 +1,6 @@
 """Scale estimation for torch tensors on an AMD GPU: the search of ScaleEstimation.calculate_quantization_params
 (src/nncf/quantization/algorithms/weight_compression/scale_estimation.py:160-377) as a sequence of fused launches --
-one per candidate scale (nncf_amd_se_step: csrc/wc_se.hip) for every group size and sample count.  What is left on
+one per candidate scale (nncf_amd_se_search -> nncf_amd_se_step: csrc/wc_se.hip) for every group size and sample count.  What is left on
 the host is shape glue: statistics -> (s, X), the grouped views, the order of the candidates and the shapes the
 reference returns."""
 from __future__ import annotations
@@ -92,21 +92,11 @@ def _search(weight, s, X, config, group_size, initial_steps, scale_steps, weight
     mode_id = _lib.MODE_ID[config.mode.value]
     dt = _lib.dtype_id(weight)
     with torch.cuda.device(dev):
-        stream = _lib.stream_of(weight)
-        _lib.check(lib.nncf_amd_se_zero_mask(_lib.ptr(wg), dt, _lib.ptr(s), _lib.ptr(scale0), _lib.ptr(zp), batch, N, G,
-                                             group_size, mode_id, _lib.ptr(zmask), _lib.ptr(rden), stream))
-
-        def step(kind, factor=1.0):
-            _lib.check(lib.nncf_amd_se_step(_lib.ptr(wg), dt, _lib.ptr(zmask), _lib.ptr(rden), _lib.ptr(s), _lib.ptr(Xg),
-                                            _lib.ptr(fp_outs), _lib.ptr(scale0), _lib.ptr(zp), _lib.ptr(best),
-                                            _lib.ptr(result), batch, N, G, group_size, n_s, mode_id, kind, factor,
-                                            ZERO_SCALE, weight_penalty, stream))
-
-        step(0)
-        for _ in range(initial_steps):
-            step(1)
-        for k in range(scale_steps):
-            step(2, 1.0 - 0.05 * k)
+        # zero mask, baseline (writes fp_outs, best, result), rectifications, grid steps: one call queues them all
+        _lib.check(lib.nncf_amd_se_search(_lib.ptr(wg), dt, _lib.ptr(zmask), _lib.ptr(rden), _lib.ptr(s), _lib.ptr(Xg),
+                                          _lib.ptr(fp_outs), _lib.ptr(scale0), _lib.ptr(zp), _lib.ptr(best),
+                                          _lib.ptr(result), batch, N, G, group_size, n_s, mode_id, initial_steps,
+                                          scale_steps, ZERO_SCALE, weight_penalty, _lib.stream_of(weight)))
     return result, zp
 
 
