@@ -206,7 +206,21 @@ def activations_to_wc_statistics(activations: Sequence[torch.Tensor]) -> WCTenso
 
 
 def process_stats(stats: WCTensorStatistic, subset_size: int, act_ch_axis: int = -1):
-    """activation_stats.py:20-57 (tiny; torch on device)."""
+    """activation_stats.py:20-57 (tiny; torch on device).  The Linears that read one activation (q / k / v, gate / up)
+    ask for the same (s, X) of the same statistics object: the result is kept on the object per (subset_size, axis)
+    while its lists are unchanged (same tensors, same shapes); callers treat s and X as read-only."""
+    cached = getattr(stats, "_processed", None)
+    means, shapes = stats.mean_values, stats.shape_values
+    if (cached is not None and cached[0] == (subset_size, act_ch_axis) and len(cached[1]) == len(means)
+            and all(a is b and v == b._version for (a, v), b in zip(cached[1], means)) and cached[2] == list(map(tuple, shapes))):
+        return cached[3]
+    result = _process_stats(stats, subset_size, act_ch_axis)
+    # (the tensors themselves are kept, not their ids: a kept tensor cannot be freed and its address handed to another)
+    stats._processed = ((subset_size, act_ch_axis), [(m, m._version) for m in means], list(map(tuple, shapes)), result)
+    return result
+
+
+def _process_stats(stats: WCTensorStatistic, subset_size: int, act_ch_axis: int = -1):
     X = torch.stack(list(stats.mean_values))
     axes = list(range(1, X.ndim)) + [0]
     X_full = X.permute(axes)

@@ -275,3 +275,27 @@ def test_int_quantization_with_precomputed_parameters(mode, pre_scale, pre_zp, r
             assert np.allclose(z, zp)
     else:
         assert z is None
+
+
+def test_process_stats_memo_follows_the_statistics():
+    """nncf_amd.statistics.process_stats keeps its result on the statistics object (the Linears reading one activation
+    ask for the same (s, X)): same object again while nothing changed; recomputed after another subset size, an
+    in-place edit of a mean, or a replaced list."""
+    import torch
+
+    from nncf_amd.statistics import WCTensorStatistic, process_stats
+
+    st = WCTensorStatistic([torch.randn(8) for _ in range(5)], [(1, 3 + i, 8) for i in range(5)])
+    a = process_stats(st, 4)
+    assert process_stats(st, 4) is a
+    c = process_stats(st, 2)
+    assert c is not a and c[1].shape[-1] == 3  # every (5 // 2)-th of the 5 samples (activation_stats.py:44-50)
+    st.mean_values[0].mul_(2)
+    d = process_stats(st, 2)
+    assert d is not c and not torch.equal(d[0], c[0])
+    st.mean_values = [m.clone() for m in st.mean_values]
+    e = process_stats(st, 2)
+    assert e is not d and torch.equal(e[0], d[0]) and torch.equal(e[1], d[1])
+    st.shape_values = [(1, 9 - i, 8) for i in range(5)]
+    f = process_stats(st, 2)
+    assert f is not e and not torch.equal(f[1], e[1])
