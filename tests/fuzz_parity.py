@@ -348,11 +348,14 @@ def check_data_aware(rng, n_cases, failures):
     from nncf_amd import awq, scale_estimation as SE
     from nncf_amd.statistics import WCTensorStatistic
     for _ in range(n_cases):
-        mode = str(rng.choice(["int4_sym", "int4_asym", "nf4", "int8_asym"]))
-        gs = int(rng.choice([32, 64, 128]))
+        mode = str(rng.choice(["int4_sym", "int4_asym", "nf4", "int8_asym", "mxfp4"]))
+        # two thirds on the tiled MFMA kernels' shapes (32 / 64 / 128, <= 64 samples), one third on everything else
+        # (k_se_step_any / k_awq_search_any: other group sizes, whole rows, more samples)
+        tiled = rng.random() < 0.67
+        gs = int(rng.choice([32, 64, 128])) if tiled else int(rng.choice([8, 16, 24, 40, 48, 96, 100, 160, 256]))
         rows = int(rng.integers(1, 300))
         K = gs * int(rng.integers(1, 9))
-        n_samples = int(rng.integers(1, 80))
+        n_samples = int(rng.integers(1, 80)) if tiled else int(rng.integers(1, 200))
         w32 = (rng.standard_normal((rows, K)) * 0.05).astype(np.float32)
         means = []
         for _i in range(n_samples):
@@ -362,18 +365,21 @@ def check_data_aware(rng, n_cases, failures):
         shapes = [(int(rng.integers(1, 30)), K) for _i in range(n_samples)]
         stats = WCTensorStatistic([torch.from_numpy(m).cuda() for m in means], shapes)
         w = torch.from_numpy(w32).cuda()
-        subset, init, steps = int(rng.choice([8, 32, 64])), int(rng.integers(1, 6)), int(rng.integers(1, 6))
-        desc = f"{mode} g{gs} {(rows, K)} samples {n_samples} subset {subset} steps {init}/{steps}"
-        sc, zp = SE.calculate_quantization_params(stats, w, (1,), _cfg(mode, gs), -1, subset, init, steps)
-        ref_s, ref_z = O.scale_estimation_params(means, shapes, w32, (1,), mode, gs, -1, subset, init, steps)
+        subset = int(rng.choice([8, 32, 64])) if tiled else int(rng.choice([8, 64, 128, 256]))
+        init, steps = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        whole_row = (not tiled) and rng.random() < 0.2
+        cfg_gs = -1 if whole_row else gs
+        desc = f"{mode} g{cfg_gs} {(rows, K)} samples {n_samples} subset {subset} steps {init}/{steps}"
+        sc, zp = SE.calculate_quantization_params(stats, w, (1,), _cfg(mode, cfg_gs), -1, subset, init, steps)
+        ref_s, ref_z = O.scale_estimation_params(means, shapes, w32, (1,), mode, cfg_gs, -1, subset, init, steps)
         close = np.isclose(host(sc), ref_s, rtol=1e-5, atol=0)
         # (a candidate whose output error ties with the best one within fp32 summation noise may go either way: one
         # group is allowed to differ whatever the group count)
         if (~close).sum() > max(1, 0.005 * close.size) or (ref_z is not None and (host(zp) != ref_z).sum() > max(1, 0.005 * close.size)):
             failures.append(f"scale estimation {desc}: {close.mean():.4f} of the scales within 1e-5")
         if mode != "int8_asym" and rng.random() < 0.5:
-            a = awq.data_aware_step(w, (1,), _cfg(mode, gs), stats, -1, subset, 0.02, 0.0, 1.0, 20)
-            ref = O.awq_data_aware_scale(w32, 1, mode, gs, means, shapes, -1, subset, 0.02, 0.0, 1.0, 20)
+            a = awq.data_aware_step(w, (1,), _cfg(mode, cfg_gs), stats, -1, subset, 0.02, 0.0, 1.0, 20)
+            ref = O.awq_data_aware_scale(w32, 1, mode, cfg_gs, means, shapes, -1, subset, 0.02, 0.0, 1.0, 20)
             ok = np.isclose(host(a), ref, rtol=1e-5, atol=0).mean()
             if ok < 0.97 and (1 - ok) * ref.size > 1:
                 failures.append(f"awq {desc}: {ok:.4f} of the channel scales within 1e-5")

@@ -129,11 +129,11 @@ def c4(args):
         def pack(name, w, q, sc, zp):
             return wl.compress_weight_packed(q.to(torch.bfloat16), (1,), cfg, CompressedWeight(None, sc, zp)).tensor
 
-        for mode, ov in (("sequential", "none"), ("unit_streams", "units"), ("next_hessian_stream", "hessian"),
-                         ("sequential_again", "none"), ("unit_streams_again", "units")):
+        for mode, ov, ms in (("sequential", "none", 1), ("unit_streams", "units", 4), ("next_hessian_stream", "hessian", 1),
+                             ("sequential_again", "none", 1), ("unit_streams_again", "units", 4)):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            res = gptq.quantize_units(units(), cfg, overlap=ov, on_weight=pack)
+            res = gptq.quantize_units(units(), cfg, overlap=ov, on_weight=pack, max_streams=ms)
             torch.cuda.synchronize()
             layer_wall[mode] = round((time.perf_counter() - t0) * 1e3, 2)
             del res
