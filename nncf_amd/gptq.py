@@ -263,7 +263,8 @@ def quantize_units(units, config: WeightCompressionConfig, damp_percent: float =
                  stream of its own: those are long chains of small dependent kernels (128-column base blocks, small
                  GEMMs of the recursion's lower levels, in-block sweeps) that leave most of the chip idle, so the
                  chains of different units interleave.  Nothing in a chain waits for the host (the Cholesky failure
-                 flags are read once at the end).  Holds every unit's Hessian / Hinv at once.
+                 flags are read once per batch).  Units are taken in batches of `max_streams`, so a batch's Hessians,
+                 Hinvs and fp32 weight copies are what is resident at once.
       "hessian"  the Hessian of unit i + 1 on a second stream under unit i's chains.  Measured on a Llama-3-70B layer
                  (tools/bench_configs.py c4): 612 -> 606 ms, the SYRK's one-wave-per-SIMD blocks leave a second queue
                  no room on a CU until they retire; kept for memory-tight callers."""
@@ -281,10 +282,8 @@ def quantize_units(units, config: WeightCompressionConfig, damp_percent: float =
                                             block_size=block_size)
             out[name] = on_weight(name, w, q, scale, zp) if on_weight is not None else (q, scale, zp)
 
-    if overlap == "units":
-        pending = [(calculate_hessian(inputs)[0], weights) for inputs, weights in units]
-        if not pending:
-            return out
+    def run_unit_batch(batch):
+        pending = [(calculate_hessian(inputs)[0], weights) for inputs, weights in batch]
         dev = pending[0][0].device
         main = torch.cuda.current_stream(dev)
         infos = torch.zeros((len(pending), 1), dtype=torch.int32, device=dev)
@@ -315,7 +314,17 @@ def quantize_units(units, config: WeightCompressionConfig, damp_percent: float =
             for t in (v if isinstance(v, (tuple, list)) else (v,)):
                 if isinstance(t, torch.Tensor):
                     t.record_stream(main)
-        return out
+        return
+
+    if overlap == "units":
+        # batches of max_streams units: what is resident at once (Hessians, Hinvs, fp32 copies of the weights) stays
+        # bounded however long the sequence is
+        it = iter(units)
+        while True:
+            batch = [u for _, u in zip(range(max(1, max_streams)), it)]
+            if not batch:
+                return out
+            run_unit_batch(batch)
 
     it = iter(units)
     dev = side = main = None
