@@ -282,24 +282,26 @@ int nncf_amd_se_search(const void* weight, int w_dtype, uint32_t* zero_mask, flo
  * in ONE launch; the host sums the tiles (fixed order) and divides by rows * n_samples to get cur_diff (:345).
  *   weight: fp32, rows of pitch row_pitch; group_offsets (DEVICE int64 [groups]): element offset of the group's first
  *   column in row 0 (+ the expert offset for 3-D weights);  scales: fp32 [groups, steps, group_size] (cur_scale, after
- *   the clamp of :315-335);  sacts = gacts[k][j] / scale[k] (:342), fp32, in the layout nncf_amd_awq_sacts_tiles names
- *   for the shape: NT = 1 / 2 / 4 (group_size in {32, 64, 128}, n_samples <= 16 / 32 / 64: the tiled MFMA kernel) ->
- *   [groups, steps, group_size, 16, NT] holding sample t*16 + c at [.., c, t], zero beyond the samples, 16-byte
- *   aligned; 0 (every other group size >= 1 / sample count) -> plain [groups, steps, group_size, n_samples];
+ *   the clamp of :315-335);  sacts = gacts[k][j] / scale[k] (:342) as nncf_amd_awq_prepare writes it, 16-byte aligned,
+ *   nncf_amd_awq_sacts_bytes(group_size, n_samples, mode) bytes per (group, step) (-1: bad argument): for group_size in
+ *   {32, 64, 128} and n_samples <= 64 the tiled MFMA kernels' layouts over NT = 1 / 2 / 4 sixteen-sample tiles (zero
+ *   beyond the samples) -- integer modes and e2m1: the exact three-way bf16 split [3][NT][group_size / 32][4][16] x 8
+ *   bf16 in the B-operand order of v_mfma_f32_16x16x32_bf16; NF4: fp32 [group_size, 16, NT] holding sample t*16 + c at
+ *   [.., c, t] -- and for every other group size >= 1 / sample count plain fp32 [group_size, n_samples];
  *   fp_out: fp32 [groups, rows, n_samples] (:307);  partial: fp32 [groups, steps, ceil(rows / 16)].
  */
-int nncf_amd_awq_sacts_tiles(int64_t group_size, int64_t n_samples);
+int64_t nncf_amd_awq_sacts_bytes(int64_t group_size, int64_t n_samples, int mode);
 /*
  * Preparation of nncf_amd_awq_search for a set of outlier groups, one launch (awq.py:311-342): per group g and alpha
  * step s the candidate scale vector cur = gscale[g] ^ alphas[s] (sqrt for 0.5), the fp16-overflow clamp of :315-335 when
  * the previous matmul is merged (gprev = mean |previous weight| of the group's channels, prev_s = max activation
  * magnitude in front of it, n_prev = its reduction length; gprev NULL: no clamp), and gacts / cur in the layout
- * nncf_amd_awq_sacts_tiles names.  gscale: fp32 [groups, group_size], clipped to [quantile 0.1, 100] (:300-301);
+ * that search reads for the shape and `mode` (above).  gscale: fp32 [groups, group_size], clipped to [quantile 0.1, 100] (:300-301);
  * gacts: fp32 [groups, group_size, n_samples];  scales: fp32 [groups, steps, group_size];  sacts: see above.
  */
 int nncf_amd_awq_prepare(const float* gscale, const float* alphas, const float* gacts, const float* gprev, float prev_s,
-                         float n_prev, int groups, int steps, int64_t group_size, int64_t n_samples, float* scales,
-                         float* sacts, void* stream);
+                         float n_prev, int groups, int steps, int64_t group_size, int64_t n_samples, int mode,
+                         float* scales, float* sacts, void* stream);
 int nncf_amd_awq_search(const float* weight, int64_t rows, int64_t row_pitch, const int64_t* group_offsets, int groups,
                         int64_t group_size, const float* scales, int steps, const float* sacts, const float* fp_out,
                         int64_t n_samples, int mode, float* partial, void* stream);

@@ -60,9 +60,9 @@ SIGNATURES = {
                                    c_float, c_float, c_void_p]),
     "nncf_amd_se_zero_mask": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                       c_int, c_void_p, c_void_p, c_void_p]),
-    "nncf_amd_awq_sacts_tiles": (c_int, [c_int64, c_int64]),
+    "nncf_amd_awq_sacts_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "nncf_amd_awq_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int64, c_int64,
-                                     c_void_p, c_void_p, c_void_p]),
+                                     c_int, c_void_p, c_void_p, c_void_p]),
     "nncf_amd_awq_search": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p,
                                     c_int64, c_int, c_void_p, c_void_p]),
     "nncf_amd_decompress": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -49,10 +49,11 @@ def _group_search(weight, s, X, config, group_size, groups, scale, alpha_min, al
     G = K // group_size
     n = X.shape[-1]
     lib = _lib.lib()
-    nt = int(lib.nncf_amd_awq_sacts_tiles(group_size, n))  # 1 / 2 / 4: the tiled kernel's layout; 0: plain
     dev = weight.device
     tiles = (N + 15) // 16
     mode_id = _lib.MODE_ID[config.mode.value]
+    # bytes of the scaled activations of one (group, step) in the layout the search kernel of this shape and mode reads
+    sacts_bytes = int(lib.nncf_amd_awq_sacts_bytes(group_size, n, mode_id))
     w4 = weight.view(B, N, G, group_size)
     alphas_t = torch.from_numpy(_alphas(alpha_min, alpha_step, steps)).to(dev)
     for c0 in range(0, len(groups), GROUPS_PER_LAUNCH):
@@ -71,12 +72,12 @@ def _group_search(weight, s, X, config, group_size, groups, scale, alpha_min, al
         # candidate scales of every alpha step incl. the fp16-overflow clamp, and gacts / scale in the search kernel's
         # layout (awq.py:311-342): one launch
         all_scales = torch.empty((nc, steps, group_size), dtype=torch.float32, device=dev)
-        sacts = torch.empty((nc, steps, group_size, 16 * nt if nt else n), dtype=torch.float32, device=dev)
+        sacts = torch.empty((nc, steps, sacts_bytes // 4), dtype=torch.float32, device=dev)
         gscale, gacts = gscale.contiguous(), gacts.contiguous()
         with torch.cuda.device(dev):
             _lib.check(lib.nncf_amd_awq_prepare(_lib.ptr(gscale), _lib.ptr(alphas_t), _lib.ptr(gacts), _lib.ptr(gprev),
                                                 float(prev_s) if prev_s is not None else 0.0, float(n_prev), nc, steps,
-                                                group_size, n, _lib.ptr(all_scales), _lib.ptr(sacts),
+                                                group_size, n, mode_id, _lib.ptr(all_scales), _lib.ptr(sacts),
                                                 _lib.stream_of(weight)))
         goff = bi * (N * K) + gi * group_size
         partial = torch.empty((nc, steps, tiles), dtype=torch.float32, device=dev)

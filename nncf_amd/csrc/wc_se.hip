@@ -1198,6 +1198,149 @@ __global__ __launch_bounds__(256) void k_awq_search(AwqArgs a) {
     }
 }
 
+// The same search for policies whose unscaled values are exact bf16 numbers (SeExact16: integer codes minus the zero
+// point, e2m1 values): cur_out = scale_row * (t @ sacts) on v_mfma_f32_16x16x32_bf16 against the three-way bf16 split of
+// sacts that k_awq_prepare wrote in the MFMA's B-operand order (3 x NT x GS/32 MFMAs of K = 32 per step instead of
+// GS/4 x NT of K = 4), and the quantization through the correctly rounded quotient (se_values_div) instead of the tie
+// test: the parameters come from these very elements, so `fast` of Policy::compute covers them.
+template <typename Par>
+__device__ __forceinline__ float awq_zsub_of(const Par& p, int) {
+    return 0.0f;
+}
+template <typename Par>
+__device__ __forceinline__ auto awq_zsub_of(const Par& p, long) -> decltype(p.zpf) {
+    return p.has_zp ? p.zpf : 0.0f;
+}
+
+// A block is AWQ16_WAVES row tiles of one group and a run of alpha steps: sacts[g, s] (the same for every tile) is
+// staged in LDS once per block and step -- read per wave from L2 it was the bound of this kernel (24 KB per wave and
+// step: 17 GB per 28 groups x 100 steps of a Llama down_proj) -- and the next step's copy is requested into registers
+// before the current step's arithmetic.
+// (4 / 8 / 8 at a forced 128 registers / 16 waves per block: 856 / 1121 / 881 / 890 us on that shape, 1156 us with
+// per-wave L2 reads; what is left is the per-element VALU work of the quantization.)
+constexpr int AWQ16_WAVES = 4;
+
+template <typename Policy, int GS, int NT>
+__global__ __launch_bounds__(AWQ16_WAVES * 64) void k_awq_search16(AwqArgs a) {
+    constexpr int QUART = GS / 4, M = GS / 32, THREADS = AWQ16_WAVES * 64;
+    constexpr int PIECE = NT * M * 1024;  // bytes of one bf16 piece of sacts[g, s]
+    constexpr int UNITS = 3 * PIECE / 16, NU = (UNITS + THREADS - 1) / THREADS;
+    __shared__ __align__(16) char buf[3 * PIECE];
+    __shared__ float lut[kPolicyLds];
+    Policy::init_shared(lut);
+    GroupArgs ga = {};
+    ga.mode = a.mode;
+    const Policy pol(ga, lut);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t N = a.rows;
+    const int g = blockIdx.z;
+    const int64_t tiles = (N + 15) / 16;
+    const int64_t tile_raw = (int64_t)blockIdx.x * AWQ16_WAVES + wave;
+    const bool active = tile_raw < tiles;  // (an idle wave still takes part in the staging and the barriers)
+    const int64_t tile = active ? tile_raw : tiles - 1;
+    const int64_t n0 = tile * 16;
+    const int s_begin = blockIdx.y * a.steps_per_block;
+    const int s_end = s_begin + a.steps_per_block < a.steps ? s_begin + a.steps_per_block : a.steps;
+    // lane (row r, quarter q) reads its QUART weights straight from the row (once per block: no LDS transpose)
+    float wv[QUART];
+    {
+        const int64_t row = n0 + r < N ? n0 + r : N - 1;
+        const float* src = a.w + a.goff[g] + row * a.K + q * QUART;
+        if ((((uintptr_t)src) & 15u) == 0) {
+#pragma unroll
+            for (int i = 0; i < QUART / 4; ++i) {
+                const float4 x = *(const float4*)(src + 4 * i);
+                wv[4 * i] = x.x, wv[4 * i + 1] = x.y, wv[4 * i + 2] = x.z, wv[4 * i + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < QUART; ++i) wv[i] = src[i];
+        }
+    }
+    const float* fo = a.fp_out + (int64_t)g * N * a.ns;
+    float fpv[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t orow = n0 + 4 * q + i;
+            const int col = t * 16 + r;
+            fpv[t][i] = (col < a.ns && orow < N) ? fo[orow * a.ns + col] : 0.0f;
+        }
+    constexpr int C = QUART < 8 ? QUART : 8;
+    const char* sa = (const char*)a.sacts + (int64_t)g * a.steps * (3 * PIECE);
+    i32x4v pre[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int unit = u * THREADS + threadIdx.x;
+        if (unit < UNITS && s_begin < s_end) pre[u] = *(const i32x4v*)(sa + (int64_t)s_begin * (3 * PIECE) + unit * 16);
+    }
+    const char* bb = buf + (q * 16 + r) * 16;
+    for (int s = s_begin; s < s_end; ++s) {
+        __syncthreads();  // the previous step's readers are done (first step: the policy table is written)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int unit = u * THREADS + threadIdx.x;
+            if (unit < UNITS) *(i32x4v*)(buf + unit * 16) = pre[u];
+        }
+        __syncthreads();
+        if (s + 1 < s_end) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int unit = u * THREADS + threadIdx.x;
+                if (unit < UNITS) pre[u] = *(const i32x4v*)(sa + (int64_t)(s + 1) * (3 * PIECE) + unit * 16);
+            }
+        }
+        const float* sc = a.scales + ((int64_t)g * a.steps + s) * GS + q * QUART;
+        float wq[QUART];
+        typename Policy::Stat st = pol.stat_init();
+#pragma unroll
+        for (int i = 0; i < QUART; i += 4) {
+            const float4 c4 = *(const float4*)(sc + i);
+            wq[i] = wv[i] * c4.x, wq[i + 1] = wv[i + 1] * c4.y, wq[i + 2] = wv[i + 2] * c4.z, wq[i + 3] = wv[i + 3] * c4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < QUART; ++i) pol.stat_add(st, wq[i]);
+        awq_stat_xor(pol, st, 16);
+        awq_stat_xor(pol, st, 32);
+        const typename Policy::Par par = pol.compute(st);
+        const float zsub = awq_zsub_of(par, 0L);
+        i32x4v Aq[M];
+#pragma unroll
+        for (int c0 = 0; c0 < QUART; c0 += C) {
+            float val[C];
+            se_values_div<C>(pol, par, wq + c0, val);
+#pragma unroll
+            for (int i = 0; i < C; i += 2) Aq[(c0 + i) / 8][((c0 + i) & 7) / 2] = pack_hi16(val[i] - zsub, val[i + 1] - zsub);
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = mfma_bf16_k32(Aq[m], *(const i32x4v*)(bb + p * PIECE + (t * M + m) * 1024), acc[t]);
+        // C layout: lane (c = lane % 16, q) holds rows 4q + i of sample column t*16 + c; row 4q + i's scale sits in
+        // lane 4q + i (every quarter of a row computed the same parameters)
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float scale_i = __shfl(par.scale, 4 * q + i, 64);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bool live = (t * 16 + r) < a.ns && (n0 + 4 * q + i) < N;
+                sum += live ? fabsf(scale_i * acc[t][i] - fpv[t][i]) : 0.0f;
+            }
+        }
+        sum = lanes_allreduce<64>(sum, OpAdd());
+        if (lane == 0 && active) a.partial[((int64_t)g * a.steps + s) * tiles + tile] = sum;
+    }
+}
+
 // Preparation of the search for a set of outlier groups (awq.py:311-342), one launch: the candidate scale vector of every
 // alpha step, cur = gscale^alpha (sqrt for alpha == 0.5, as `tensor ** 0.5` evaluates), the fp16-overflow clamp when the
 // previous matmul absorbs 1 / scale (:315-335: where the scaled previous weight would leave a quarter of the fp16 range,
@@ -1209,10 +1352,28 @@ struct AwqPrepArgs {
     const float* gacts;   // [groups, gs, ns]
     const float* gprev;   // [groups, gs] mean |previous weight| per channel, or NULL (no merged matmul)
     float* scales;        // [groups, steps, gs]
-    float* sacts;         // tiles > 0: [groups, steps, gs, 16, tiles]; tiles == 0: [groups, steps, gs, ns]
-    int gs, ns, steps, tiles;
+    float* sacts;         // AwqLayout of the shape and mode
+    int gs, ns, steps, tiles, split;
     float prev_s, n_prev;
 };
+
+// Layout of `sacts` per (group, step):
+//   tiles == 0           plain [gs, ns] fp32 (k_awq_search_any)
+//   tiles > 0, !split    [gs, 16, tiles] fp32 (k_awq_search: NF4)
+//   tiles > 0, split     [3 pieces][tiles][gs / 32][4 quarters][16 columns] x 8 bf16: the exact three-way bf16 split in
+//                        the B-operand order of v_mfma_f32_16x16x32_bf16 (k_awq_search16: integer modes, e2m1)
+struct AwqLayout {
+    int tiles;
+    bool split;
+    int64_t bytes(int64_t gs, int64_t ns) const {
+        if (tiles == 0) return gs * ns * 4;
+        return split ? 3 * tiles * gs * 32 : gs * 16 * tiles * 4;
+    }
+};
+static AwqLayout awq_layout(int64_t gs, int64_t ns, int mode) {
+    if (!nncf_amd_se_step_supported(gs, ns)) return {0, false};
+    return {ns <= 16 ? 1 : (ns <= 32 ? 2 : 4), mode != NNCF_AMD_NF4};
+}
 
 __global__ __launch_bounds__(256) void k_awq_prepare(AwqPrepArgs a) {
     extern __shared__ float cur[];  // [gs]
@@ -1241,7 +1402,27 @@ __global__ __launch_bounds__(256) void k_awq_prepare(AwqPrepArgs a) {
     float* so = a.scales + ((int64_t)g * a.steps + s) * gs;
     for (int k = threadIdx.x; k < gs; k += 256) so[k] = cur[k];
     const float* ga = a.gacts + (int64_t)g * gs * ns;
-    if (a.tiles > 0) {
+    if (a.tiles > 0 && a.split) {
+        // one thread writes the bf16 pair (k, k + 1) of a sample column in each of the three pieces (4-byte stores,
+        // consecutive threads consecutive words)
+        const int M = gs / 32, quart = gs / 4, piece = a.tiles * M * 1024;
+        char* out = (char*)a.sacts + ((int64_t)g * a.steps + s) * 3 * piece;
+        for (int idx = threadIdx.x; idx < piece / 4; idx += 256) {
+            const int i2 = idx & 3, c = (idx >> 2) & 15, qq = (idx >> 6) & 3, m = (idx >> 8) % M, t = (idx >> 8) / M;
+            const int k = qq * quart + m * 8 + i2 * 2, j = t * 16 + c;
+            uint32_t word[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float x = j < ns ? ga[(k + e) * ns + j] / cur[k + e] : 0.0f;
+                const float h = hi16_of(x), r1 = x - h, mm = hi16_of(r1), l = r1 - mm;  // exact: 8 + 8 + 8 significand bits
+                word[0] |= (__builtin_bit_cast(uint32_t, h) >> 16) << (16 * e);
+                word[1] |= (__builtin_bit_cast(uint32_t, mm) >> 16) << (16 * e);
+                word[2] |= (__builtin_bit_cast(uint32_t, l) >> 16) << (16 * e);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *(uint32_t*)(out + p * piece + idx * 4) = word[p];
+        }
+    } else if (a.tiles > 0) {
         const int width = 16 * a.tiles;  // per k: [16 columns][tiles], sample t*16 + c at c * tiles + t
         float* out = a.sacts + ((int64_t)g * a.steps + s) * gs * width;
         for (int idx = threadIdx.x; idx < gs * width; idx += 256) {
@@ -1256,11 +1437,14 @@ __global__ __launch_bounds__(256) void k_awq_prepare(AwqPrepArgs a) {
 
 }  // namespace wc
 
-extern "C" int nncf_amd_awq_sacts_tiles(int64_t group_size, int64_t n_samples);
+extern "C" int64_t nncf_amd_awq_sacts_bytes(int64_t group_size, int64_t n_samples, int mode) {
+    if (group_size < 1 || n_samples < 1 || n_samples > 0x7fffffff / group_size) return -1;
+    return wc::awq_layout(group_size, n_samples, mode).bytes(group_size, n_samples);
+}
 
 extern "C" int nncf_amd_awq_prepare(const float* gscale, const float* alphas, const float* gacts, const float* gprev,
                                     float prev_s, float n_prev, int groups, int steps, int64_t group_size,
-                                    int64_t n_samples, float* scales, float* sacts, void* stream) {
+                                    int64_t n_samples, int mode, float* scales, float* sacts, void* stream) {
     using namespace wc;
     if (groups < 0 || steps < 0 || group_size < 1 || n_samples < 1 || n_samples > 0x7fffffff / group_size) {
         set_error("awq_prepare: bad argument");
@@ -1275,8 +1459,9 @@ extern "C" int nncf_amd_awq_prepare(const float* gscale, const float* alphas, co
         set_error("awq_prepare: NULL buffer or more than 65535 groups");
         return NNCF_AMD_ERR_BAD_ARG;
     }
+    const AwqLayout lay = awq_layout(group_size, n_samples, mode);
     AwqPrepArgs a = {gscale, alphas, gacts, gprev, scales, sacts, (int)group_size, (int)n_samples, steps,
-                     nncf_amd_awq_sacts_tiles(group_size, n_samples), prev_s, n_prev};
+                     lay.tiles, lay.split ? 1 : 0, prev_s, n_prev};
     static OncePerDevice attr_once;
     if (attr_once.first_on_device() != 0) {
         if (hipFuncSetAttribute((const void*)k_awq_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, 160000) != hipSuccess) {
@@ -1406,6 +1591,16 @@ template <typename Policy, int GS>
 static int awq_launch(const AwqArgs& a, int groups, hipStream_t s) {
     const int64_t tiles = (a.rows + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)((a.steps + a.steps_per_block - 1) / a.steps_per_block), (unsigned)groups);
+    if constexpr (SeExact16<Policy>::value) {
+        const dim3 grid16((unsigned)((tiles + AWQ16_WAVES - 1) / AWQ16_WAVES), grid.y, grid.z), block16(AWQ16_WAVES * 64);
+        if (a.ns <= 16)
+            hipLaunchKernelGGL((k_awq_search16<Policy, GS, 1>), grid16, block16, 0, s, a);
+        else if (a.ns <= 32)
+            hipLaunchKernelGGL((k_awq_search16<Policy, GS, 2>), grid16, block16, 0, s, a);
+        else
+            hipLaunchKernelGGL((k_awq_search16<Policy, GS, 4>), grid16, block16, 0, s, a);
+        return launch_status("awq_search (bf16 MFMA)");
+    }
     if (a.ns <= 16)
         hipLaunchKernelGGL((k_awq_search<Policy, GS, 1>), grid, dim3(256), 0, s, a);
     else if (a.ns <= 32)
@@ -1428,13 +1623,6 @@ static int awq_gs(const AwqArgs& a, int groups, int64_t gs, hipStream_t s) {
 
 }  // namespace wc
 
-// Layout of `sacts` for a shape: NT = 1 / 2 / 4 -> the tiled kernel's [groups, steps, group_size, 16, NT]; 0 -> the
-// plain [groups, steps, group_size, n_samples] of the `_any` kernel.
-extern "C" int nncf_amd_awq_sacts_tiles(int64_t group_size, int64_t n_samples) {
-    if (!nncf_amd_se_step_supported(group_size, n_samples)) return 0;
-    return n_samples <= 16 ? 1 : (n_samples <= 32 ? 2 : 4);
-}
-
 extern "C" int nncf_amd_awq_search(const float* weight, int64_t rows, int64_t row_pitch, const int64_t* group_offsets,
                                    int groups, int64_t group_size, const float* scales, int steps, const float* sacts,
                                    const float* fp_out, int64_t n_samples, int mode, float* partial, void* stream) {
@@ -1453,14 +1641,16 @@ extern "C" int nncf_amd_awq_search(const float* weight, int64_t rows, int64_t ro
         set_error("awq_search: more than 65535 groups per launch (%d): split the list", groups);
         return NNCF_AMD_ERR_UNSUPPORTED;
     }
-    if (nncf_amd_awq_sacts_tiles(group_size, n_samples) != 0 && (((uintptr_t)scales | (uintptr_t)sacts) & 15u)) {
+    if (awq_layout(group_size, n_samples, mode).tiles != 0 && (((uintptr_t)scales | (uintptr_t)sacts) & 15u)) {  // (tiled kernels)
         set_error("awq_search: scales / sacts must be 16-byte aligned");
         return NNCF_AMD_ERR_BAD_ARG;
     }
     // enough blocks to fill the chip: split the alpha steps of a tile over blocks when there are few row tiles
     const int64_t tiles = (rows + 15) / 16;
-    const int64_t blocks_per_chunk = ((tiles + 3) / 4) * groups;
-    int chunks = (int)((2048 + blocks_per_chunk - 1) / blocks_per_chunk);
+    const AwqLayout lay = awq_layout(group_size, n_samples, mode);
+    const bool wide = lay.tiles != 0 && lay.split;  // k_awq_search16: AWQ16_WAVES tiles per block
+    const int64_t blocks_per_chunk = (wide ? (tiles + AWQ16_WAVES - 1) / AWQ16_WAVES : (tiles + 3) / 4) * groups;
+    int chunks = (int)(((wide ? 1024 : 2048) + blocks_per_chunk - 1) / blocks_per_chunk);
     if (chunks < 1) chunks = 1;
     if (chunks > steps) chunks = steps;
     AwqArgs a = {weight, group_offsets, scales, sacts, fp_out, partial, rows, row_pitch, steps, (int)n_samples, mode,

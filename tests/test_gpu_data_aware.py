@@ -497,7 +497,8 @@ def test_gptq_against_the_independent_autogptq_reference(golden):
 @pytest.mark.parametrize("merged", [False, True])
 @pytest.mark.parametrize("mode,gs,n_samples,subset", [("int4_sym", 128, 32, 32), ("int4_asym", 64, 40, 64), ("nf4", 32, 9, 32),
                                                        ("int8_asym", 128, 64, 64), ("int4_asym", 48, 20, 32), ("int4_sym", 100, 70, 128),
-                                                       ("nf4", -1, 12, 32), ("int4_sym", 64, 90, 128), ("mxfp4", 10, 5, 32)])
+                                                       ("nf4", -1, 12, 32), ("int4_sym", 64, 90, 128), ("mxfp4", 10, 5, 32),
+                                                       ("mxfp4", 32, 24, 32), ("int4_sym", 32, 12, 32)])
 def test_awq_search_matches_oracle(mode, gs, n_samples, subset, merged):
     """nncf_amd_awq_search (all groups x alpha steps in one launch; the tiled MFMA kernel for group sizes 32 / 64 / 128
     with <= 64 samples, k_awq_search_any for every other shape) against the oracle's restatement of awq.py:243-357,
