@@ -266,7 +266,9 @@ int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t* zero_mask,
 /*
  * The whole search of scale_estimation.py:236-360 for one weight in one call: nncf_amd_se_zero_mask, then
  * nncf_amd_se_step kind 0, `initial_steps` x kind 1, `scale_steps` x kind 2 with factor 1 - 0.05 k (:301), queued back
- * to back on `stream`.  Same buffers as those two (zero_mask / rden are scratch the call fills itself).
+ * to back on `stream`.  Same buffers as those two (zero_mask / rden are scratch the call fills itself: on the tiled
+ * shapes of the integer modes and e2m1 the kind-0 step writes them while it quantizes with the min-max parameters, so
+ * the separate pass over the weight is not launched).
  */
 int nncf_amd_se_search(const void* weight, int w_dtype, uint32_t* zero_mask, float* rden, const float* s_per_channel,
                        const float* x, float* fp_outs, const float* scale0, const float* zero_point, float* best_diffs,

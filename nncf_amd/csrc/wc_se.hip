@@ -45,6 +45,8 @@ struct SeStepArgs {
     int ns, mode, kind;
     float factor, zero_scale, weight_penalty;
     int64_t batch;
+    uint32_t* zmask_out;    // kind 0 of k_se_step16 only, or NULL: the baseline step also writes zmask / rden (it
+    float* rden_out;        // quantizes with the min-max parameters anyway: no separate pass over the weight)
 };
 
 template <int M>
@@ -479,7 +481,7 @@ __global__ __launch_bounds__((Se16Shape<DT, GS>::kThreads)) void k_se_step16(SeS
             *(uint16_t*)(Bx + SH::kPiece + off) = (uint16_t)(__builtin_bit_cast(uint32_t, m) >> 16);
             *(uint16_t*)(Bx + 2 * SH::kPiece + off) = (uint16_t)(__builtin_bit_cast(uint32_t, l) >> 16);
         }
-        if (threadIdx.x < GS) ssh[threadIdx.x] = !BASE ? a.s[(e * G + g) * GS + threadIdx.x] : 0.0f;
+        if (threadIdx.x < GS) ssh[threadIdx.x] = (!BASE || a.zmask_out) ? a.s[(e * G + g) * GS + threadIdx.x] : 0.0f;
       }
       __syncthreads();
       float* fo = a.fp_outs + ((e * G + g) * N) * ns;
@@ -528,6 +530,8 @@ __global__ __launch_bounds__((Se16Shape<DT, GS>::kThreads)) void k_se_step16(SeS
         se_guard(pol, pn, amax);
         i32x4v Aq[M];
         float pen = 0.0f;
+        uint32_t zbits = 0;   // BASE with zmask_out: the zero mask of this min-max quantization and the unmasked sum of s
+        float ssum = 0.0f;
 #pragma unroll
         for (int c0 = 0; c0 < QUART; c0 += C) {
             float val[C];
@@ -540,8 +544,31 @@ __global__ __launch_bounds__((Se16Shape<DT, GS>::kThreads)) void k_se_step16(SeS
                     pen += d * d;
                 }
             }
+            if constexpr (BASE) {
+                if (a.zmask_out) {  // uniform
+                    float sch[C];
+#pragma unroll
+                    for (int i = 0; i < C; i += 4) *(float4*)(sch + i) = *(const float4*)(ssh + q * QUART + c0 + i);
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        const bool zero = val[i] == 0.0f;  // isclose(target, 0) for integer / e2m1 targets
+                        zbits |= zero ? (1u << (c0 + i)) : 0u;
+                        ssum += zero ? 0.0f : sch[i];
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < C; i += 2) Aq[(c0 + i) / 8][((c0 + i) & 7) / 2] = pack_hi16(val[i], val[i + 1]);
+        }
+        if constexpr (BASE) {
+            if (a.zmask_out) {
+                ssum += __shfl_xor(ssum, 16, 64);
+                ssum += __shfl_xor(ssum, 32, 64);
+                if (row < N) {
+                    a.zmask_out[pidx * 4 + q] = zbits;
+                    if (q == 0) a.rden_out[pidx] = 1.0f / (ssum + kEps);
+                }
+            }
         }
         f32x4 acc[NT];
 #pragma unroll
@@ -920,11 +947,11 @@ extern "C" int nncf_amd_se_step_supported(int64_t group_size, int64_t n_samples)
     return (group_size == 32 || group_size == 64 || group_size == 128) && n_samples >= 1 && n_samples <= 64;
 }
 
-extern "C" int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t* zero_mask, const float* rden,
-                                const float* s_per_channel, const float* x, float* fp_outs, const float* scale0,
-                                const float* zero_point, float* best_diffs, float* result_scale, int64_t batch,
-                                int64_t rows, int64_t groups, int64_t group_size, int64_t n_samples, int mode, int kind,
-                                float factor, float zero_scale, float weight_penalty, void* stream) {
+static int se_step_impl(const void* weight, int w_dtype, const uint32_t* zero_mask, const float* rden,
+                        const float* s_per_channel, const float* x, float* fp_outs, const float* scale0,
+                        const float* zero_point, float* best_diffs, float* result_scale, int64_t batch, int64_t rows,
+                        int64_t groups, int64_t group_size, int64_t n_samples, int mode, int kind, float factor,
+                        float zero_scale, float weight_penalty, void* stream, uint32_t* zmask_out, float* rden_out) {
     using namespace wc;
     if (batch < 0 || rows < 0 || groups < 0 || kind < 0 || kind > 2 || group_size < 1 || n_samples < 1 ||
         n_samples > 0x7fffffff) {
@@ -939,7 +966,7 @@ extern "C" int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t*
         return NNCF_AMD_ERR_BAD_ARG;
     }
     SeStepArgs a = {weight, zero_mask, rden, s_per_channel, x, fp_outs, scale0, zero_point, best_diffs, result_scale,
-                    rows, groups, (int)n_samples, mode, kind, factor, zero_scale, weight_penalty, batch};
+                    rows, groups, (int)n_samples, mode, kind, factor, zero_scale, weight_penalty, batch, zmask_out, rden_out};
     hipStream_t s = (hipStream_t)stream;
     if (mode >= NNCF_AMD_INT8_ASYM && mode <= NNCF_AMD_INT4_SYM) {
         const bool asym = mode == NNCF_AMD_INT8_ASYM || mode == NNCF_AMD_INT4_ASYM;
@@ -955,6 +982,16 @@ extern "C" int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t*
     if (mode == NNCF_AMD_MXFP4 || mode == NNCF_AMD_FP4) return se_step_dt<FloatPolicy<false>>(a, w_dtype, batch, group_size, s);
     set_error("se_step: unsupported mode %d", mode);
     return NNCF_AMD_ERR_MODE;
+}
+
+extern "C" int nncf_amd_se_step(const void* weight, int w_dtype, const uint32_t* zero_mask, const float* rden,
+                                const float* s_per_channel, const float* x, float* fp_outs, const float* scale0,
+                                const float* zero_point, float* best_diffs, float* result_scale, int64_t batch,
+                                int64_t rows, int64_t groups, int64_t group_size, int64_t n_samples, int mode, int kind,
+                                float factor, float zero_scale, float weight_penalty, void* stream) {
+    return se_step_impl(weight, w_dtype, zero_mask, rden, s_per_channel, x, fp_outs, scale0, zero_point, best_diffs,
+                        result_scale, batch, rows, groups, group_size, n_samples, mode, kind, factor, zero_scale,
+                        weight_penalty, stream, nullptr, nullptr);
 }
 
 template <typename Policy>
@@ -1026,6 +1063,8 @@ extern "C" int nncf_amd_se_zero_mask(const void* weight, int w_dtype, const floa
 // The whole search of one weight in ONE call: zero mask, baseline, `initial_steps` rectifications, `scale_steps` grid
 // candidates (factor 1 - 0.05 k, scale_estimation.py:301) -- the same launches nncf_amd_se_zero_mask / nncf_amd_se_step
 // make, queued back to back from here instead of one FFI round trip each (12 per weight with the reference's defaults).
+// (Zero mask inside the baseline step of k_se_step16: 49.7 -> 57.9 us for that step, a 37.9 us pass less, per weight
+// of the Llama-3-8B layer mix.)
 extern "C" int nncf_amd_se_search(const void* weight, int w_dtype, uint32_t* zero_mask, float* rden,
                                   const float* s_per_channel, const float* x, float* fp_outs, const float* scale0,
                                   const float* zero_point, float* best_diffs, float* result_scale, int64_t batch,
@@ -1035,13 +1074,20 @@ extern "C" int nncf_amd_se_search(const void* weight, int w_dtype, uint32_t* zer
         wc::set_error("se_search: negative step count");
         return NNCF_AMD_ERR_BAD_ARG;
     }
-    int st = nncf_amd_se_zero_mask(weight, w_dtype, s_per_channel, scale0, zero_point, batch, rows, groups, group_size, mode,
+    // k_se_step16's baseline step (tiled shapes, integer modes and e2m1) writes the zero mask itself; the other kernels
+    // take it from the separate pass (NF4) or rebuild it (`_any`)
+    const bool fused_mask = wc::se_tiled_shape(group_size, n_samples, groups, batch, weight) && mode != NNCF_AMD_NF4 &&
+                            (w_dtype == NNCF_AMD_F32 || w_dtype == NNCF_AMD_BF16) && s_per_channel && zero_mask && rden;
+    int st = NNCF_AMD_OK;
+    if (!fused_mask)
+        st = nncf_amd_se_zero_mask(weight, w_dtype, s_per_channel, scale0, zero_point, batch, rows, groups, group_size, mode,
                                    zero_mask, rden, stream);
     if (st != NNCF_AMD_OK) return st;
     auto step = [&](int kind, float factor) {
-        return nncf_amd_se_step(weight, w_dtype, zero_mask, rden, s_per_channel, x, fp_outs, scale0, zero_point, best_diffs,
-                                result_scale, batch, rows, groups, group_size, n_samples, mode, kind, factor, zero_scale,
-                                weight_penalty, stream);
+        const bool base = kind == 0 && fused_mask;
+        return se_step_impl(weight, w_dtype, zero_mask, rden, s_per_channel, x, fp_outs, scale0, zero_point, best_diffs,
+                            result_scale, batch, rows, groups, group_size, n_samples, mode, kind, factor, zero_scale,
+                            weight_penalty, stream, base ? zero_mask : nullptr, base ? rden : nullptr);
     };
     if ((st = step(0, 1.0f)) != NNCF_AMD_OK) return st;
     for (int i = 0; i < initial_steps; ++i)
