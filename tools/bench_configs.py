@@ -60,9 +60,8 @@ def c3(args):
     for it in range(4):  # one warm-up pass, then three timed ones: the median per phase is reported
         ph.ms = {}
         stats = {}
-        for key, acts in (("a", acts_h), ("b", acts_h), ("c", acts_h), ("d", acts_i)):
-            stats[key] = ph.run("statistics (4 activations x %d samples)" % args.samples,
-                                lambda: S.activations_to_wc_statistics(acts))
+        stats = ph.run("statistics (4 activations x %d samples)" % args.samples, lambda: {
+            key: S.activations_to_wc_statistics(acts) for key, acts in (("a", acts_h), ("b", acts_h), ("c", acts_h), ("d", acts_i))})
         # AWQ: the MatMul -> Multiply -> MatMul pattern of the gated MLP (target down_proj, merged into up_proj)
         scale = ph.run("awq search (down_proj)", lambda: awq.data_aware_step(
             W["down"].float(), (1,), cfg, stats["d"], prev_weight=W["up"], prev_statistics=stats["c"]))
@@ -71,13 +70,12 @@ def c3(args):
         Wl = dict(W)
         Wl["down"], Wl["up"] = wd
         stats["d"] = S.WCTensorStatistic([m / scale.to(m.dtype) for m in stats["d"].mean_values], stats["d"].shape_values)
-        pre = {}
-        for n in shapes:
-            pre[n] = ph.run("scale estimation (7 weights)", lambda: se.calculate_quantization_params(
-                stats[reads[n]], Wl[n], (1,), cfg, subset_size=64, initial_steps=5, scale_steps=5))
-        for n in shapes:
-            ph.run("lowering + pack with the estimated scales", lambda: wl.compress_weight_packed(
-                Wl[n], (1,), cfg, CompressedWeight(None, pre[n][0], pre[n][1])))
+        # the seven weights of a phase are queued back to back, as the model-level driver does (one device
+        # synchronisation per phase, not per weight)
+        pre = ph.run("scale estimation (7 weights)", lambda: {n: se.calculate_quantization_params(
+            stats[reads[n]], Wl[n], (1,), cfg, subset_size=64, initial_steps=5, scale_steps=5) for n in shapes})
+        ph.run("lowering + pack with the estimated scales", lambda: [wl.compress_weight_packed(
+            Wl[n], (1,), cfg, CompressedWeight(None, pre[n][0], pre[n][1])) for n in shapes])
         if it > 0:
             passes.append(dict(ph.ms))
     ph.ms = {k: sorted(p[k] for p in passes)[len(passes) // 2] for k in passes[0]}
