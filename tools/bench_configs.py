@@ -118,6 +118,7 @@ def c4(args):
             ph.run("lowering + pack with the GPTQ scales", lambda: wl.compress_weight_packed(
                 q.to(torch.bfloat16), (1,), cfg, CompressedWeight(None, sc, zp)))
         del hinv
+        print("c4: unit %s done, phases so far %s" % (key, {k: round(v, 1) for k, v in ph.ms.items()}), file=sys.stderr, flush=True)
     total = sum(ph.ms.values())
     # the same layer through the product's unit pipeline (gptq.quantize_units): Hessian of unit i + 1 on a second
     # stream under unit i's Hinv and sweeps; activations of all four units resident before the clock starts
@@ -139,6 +140,7 @@ def c4(args):
             res = gptq.quantize_units(units(), cfg, overlap=ov, on_weight=pack, max_streams=ms)
             torch.cuda.synchronize()
             layer_wall[mode] = round((time.perf_counter() - t0) * 1e3, 2)
+            print("c4: %s %.1f ms" % (mode, layer_wall[mode]), file=sys.stderr, flush=True)
             del res
     return {"config": "c4: Llama-3-70B layer, %s g64, gptq, %d x %d tokens bf16" % (args.mode, args.samples, args.tokens),
             "phases_ms": {k: round(v, 3) for k, v in ph.ms.items()}, "layer_ms": round(total, 3),
