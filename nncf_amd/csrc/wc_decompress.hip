@@ -114,39 +114,25 @@ __global__ __launch_bounds__(256) void k_decompress8(const uint8_t* __restrict__
 //     inside a span (< 2^24 vectors) the division is a shift or a float multiply with one correction.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
+// what a thread reads for one vector of 8 elements: the codes (p1: INT8 only), the raw scale (fp16 bits or E8M0 byte) and
+// the raw zero-point byte of its group
+struct HVec {
+    uint32_t p0, p1, sraw, zraw;
+    uint64_t g, e0;
+    bool ok;
+};
+
 template <int MODE, int OUT_DT>
-__global__ __launch_bounds__(256) void k_decompress_h(const uint8_t* __restrict__ codes, const void* __restrict__ scale,
-                                                      const uint8_t* __restrict__ zp, void* __restrict__ out, uint64_t n_vec,
-                                                      uint32_t d, uint32_t span_groups, float rcp_d, int shift) {
-    __shared__ _Float16 lut[16];
-    if constexpr (MODE == NNCF_AMD_NF4) {
-        if (threadIdx.x < 16) lut[threadIdx.x] = (_Float16)kNF4Q[threadIdx.x];
-        __syncthreads();
-    }
-    const uint32_t vl = blockIdx.x * 256 + threadIdx.x;  // vector of 8 elements inside the span
-    const uint32_t span_vec = span_groups * d;
-    uint32_t gl;
-    if (shift >= 0) {
-        gl = vl >> shift;
-    } else {
-        gl = (uint32_t)((float)vl * rcp_d);  // within 1 of vl / d (vl < 2^24)
-        const uint32_t r = vl - gl * d;
-        if ((int32_t)r < 0) --gl;
-        else if (r >= d) ++gl;
-    }
-    const uint64_t v = (uint64_t)blockIdx.y * span_vec + vl;
-    if (vl >= span_vec || v >= n_vec) return;
-    const uint64_t g = (uint64_t)blockIdx.y * span_groups + gl;
-    const uint64_t e0 = v * 8;
+__device__ __forceinline__ void decompress_h_vec(const HVec& in, const h2* lut, void* __restrict__ out) {
     float r[8];
     if constexpr (MODE == NNCF_AMD_MXFP4) {
         // scale 2^(byte - 127) times the 2^14 of the code's fp16 image: one exact power of two while it is finite
         // (byte <= 240); the few bytes above take the two factors one after the other
-        const uint32_t byte = ((const uint8_t*)scale)[g];
+        const uint32_t byte = in.sraw;
         const bool wide = byte > 240u;
         const float s = wide ? e8m0_scale(byte) : __builtin_bit_cast(float, (byte + 14u) << 23);
         const float pre = wide ? 16384.0f : 1.0f;
-        const uint32_t p = *(const uint32_t*)(codes + e0 / 2);
+        const uint32_t p = in.p0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t q = p >> (4 * k);
@@ -164,25 +150,22 @@ __global__ __launch_bounds__(256) void k_decompress_h(const uint8_t* __restrict_
             }
         }
     } else {
-        const _Float16 s = __builtin_bit_cast(_Float16, ((const uint16_t*)scale)[g]);
+        const _Float16 s = __builtin_bit_cast(_Float16, (uint16_t)in.sraw);
         const h2 s2 = {s, s};
         h2 h[4];
         if constexpr (MODE == NNCF_AMD_NF4) {
-            const uint32_t p = *(const uint32_t*)(codes + e0 / 2);
+            const uint32_t p = in.p0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const h2 q = {lut[(p >> (8 * k)) & 15], lut[(p >> (8 * k + 4)) & 15]};
-                h[k] = q * s2;  // elements 2k, 2k + 1
-            }
+            for (int k = 0; k < 4; ++k) h[k] = lut[(p >> (8 * k)) & 255u] * s2;  // elements 2k, 2k + 1
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 r[2 * k] = (float)h[k].x;
                 r[2 * k + 1] = (float)h[k].y;
             }
         } else if constexpr (MODE == NNCF_AMD_INT4_SYM || MODE == NNCF_AMD_INT4_ASYM) {
-            const uint32_t p = *(const uint32_t*)(codes + e0 / 2);
+            const uint32_t p = in.p0;
             uint32_t z = 8;  // INT4_SYM: codes are stored with a +8 bias (pack_int4)
-            if constexpr (MODE == NNCF_AMD_INT4_ASYM) z = (zp[g >> 1] >> (4 * (g & 1))) & 15;
+            if constexpr (MODE == NNCF_AMD_INT4_ASYM) z = (in.zraw >> (4 * (in.g & 1))) & 15;
             const _Float16 zb = __builtin_bit_cast(_Float16, (uint16_t)(0x6400u | z));
             const h2 zb2 = {zb, zb};
 #pragma unroll
@@ -196,10 +179,9 @@ __global__ __launch_bounds__(256) void k_decompress_h(const uint8_t* __restrict_
                 r[k + 4] = (float)h[k].y;
             }
         } else {
-            const uint2 pp = *(const uint2*)(codes + e0);
-            uint32_t w[2] = {pp.x, pp.y};
+            uint32_t w[2] = {in.p0, in.p1};
             uint32_t z = 128;  // INT8_SYM: the sign bit is flipped, code + 128
-            if constexpr (MODE == NNCF_AMD_INT8_ASYM) z = zp[g];
+            if constexpr (MODE == NNCF_AMD_INT8_ASYM) z = in.zraw;
             else {
                 w[0] ^= 0x80808080u;
                 w[1] ^= 0x80808080u;
@@ -220,7 +202,57 @@ __global__ __launch_bounds__(256) void k_decompress_h(const uint8_t* __restrict_
             }
         }
     }
-    store8<OUT_DT>(out, (int64_t)e0, r);
+    store8<OUT_DT>(out, (int64_t)in.e0, r);
+}
+
+// ITERS chunks of 256 vectors per block, all of a thread's reads requested before the first is used: with one vector
+// per thread (4 bytes in, 16 out) the kernel is bound by the latency of that one read times the resident waves --
+// 5.2-5.3 TB/s on a 28672 x 8192 weight (out of the caches; a plain fill of the output reaches 6.9), NF4 4.4 with its
+// table prologue (constant loads, LDS writes and a barrier in front of 2048 elements of work).
+template <int MODE, int OUT_DT, int ITERS>
+__global__ __launch_bounds__(256) void k_decompress_h(const uint8_t* __restrict__ codes, const void* __restrict__ scale,
+                                                      const uint8_t* __restrict__ zp, void* __restrict__ out, uint64_t n_vec,
+                                                      uint32_t d, uint32_t span_groups, float rcp_d, int shift) {
+    // NF4: one LDS entry per code BYTE (the fp16 pair of its two nibbles): one 4-byte read per two elements
+    __shared__ h2 lut[MODE == NNCF_AMD_NF4 ? 256 : 1];
+    if constexpr (MODE == NNCF_AMD_NF4) {
+        lut[threadIdx.x] = h2{(_Float16)kNF4Q[threadIdx.x & 15], (_Float16)kNF4Q[threadIdx.x >> 4]};
+        __syncthreads();
+    }
+    const uint32_t span_vec = span_groups * d;
+    HVec in[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const uint32_t vl = (blockIdx.x * ITERS + it) * 256 + threadIdx.x;  // vector of 8 elements inside the span
+        uint32_t gl;
+        if (shift >= 0) {
+            gl = vl >> shift;
+        } else {
+            gl = (uint32_t)((float)vl * rcp_d);  // within 1 of vl / d (vl < 2^24)
+            const uint32_t r = vl - gl * d;
+            if ((int32_t)r < 0) --gl;
+            else if (r >= d) ++gl;
+        }
+        const uint64_t v = (uint64_t)blockIdx.y * span_vec + vl;
+        HVec& x = in[it];
+        x.ok = vl < span_vec && v < n_vec;
+        x.g = x.ok ? (uint64_t)blockIdx.y * span_groups + gl : 0;  // (a vector past the end reads vector 0: no branch)
+        x.e0 = (x.ok ? v : 0) * 8;
+        x.p1 = x.zraw = 0;
+        if constexpr (MODE == NNCF_AMD_INT8_ASYM || MODE == NNCF_AMD_INT8_SYM) {
+            const uint2 pp = *(const uint2*)(codes + x.e0);
+            x.p0 = pp.x, x.p1 = pp.y;
+        } else {
+            x.p0 = *(const uint32_t*)(codes + x.e0 / 2);
+        }
+        if constexpr (MODE == NNCF_AMD_MXFP4) x.sraw = ((const uint8_t*)scale)[x.g];
+        else x.sraw = ((const uint16_t*)scale)[x.g];
+        if constexpr (MODE == NNCF_AMD_INT4_ASYM) x.zraw = zp[x.g >> 1];
+        if constexpr (MODE == NNCF_AMD_INT8_ASYM) x.zraw = zp[x.g];
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+        if (in[it].ok) decompress_h_vec<MODE, OUT_DT>(in[it], lut, out);
 }
 
 // any group size / alignment: one thread per element (correctness path)
@@ -299,10 +331,17 @@ extern "C" int nncf_amd_decompress(const uint8_t* codes, int mode, int64_t n_gro
                 shift = 0;
                 while (((uint64_t)1 << shift) < d) ++shift;
             }
-            const dim3 grid((unsigned)((span_groups * d + 255) / 256), (unsigned)spans);
+            const uint64_t chunks = (span_groups * d + 255) / 256;  // of 256 vectors, per span
+            // with enough blocks to go round: 4 chunks per block
+            const int iters = chunks * spans >= 8192 ? 4 : 1;
+            const dim3 grid((unsigned)((chunks + iters - 1) / iters), (unsigned)spans);
 #define LAUNCH_H(M, DT)                                                                                                     \
-    hipLaunchKernelGGL((k_decompress_h<M, DT>), grid, dim3(256), 0, s, codes, scale, zero_point, out, n_vec, (uint32_t)d,  \
-                       (uint32_t)span_groups, 1.0f / (float)d, shift)
+    if (iters == 4)                                                                                                         \
+        hipLaunchKernelGGL((k_decompress_h<M, DT, 4>), grid, dim3(256), 0, s, codes, scale, zero_point, out, n_vec,         \
+                           (uint32_t)d, (uint32_t)span_groups, 1.0f / (float)d, shift);                                    \
+    else                                                                                                                    \
+        hipLaunchKernelGGL((k_decompress_h<M, DT, 1>), grid, dim3(256), 0, s, codes, scale, zero_point, out, n_vec,         \
+                           (uint32_t)d, (uint32_t)span_groups, 1.0f / (float)d, shift)
 #define LAUNCH_HM(DT)                                                                                                       \
     switch (mode) {                                                                                                         \
         case NNCF_AMD_INT8_ASYM: LAUNCH_H(NNCF_AMD_INT8_ASYM, DT); break;                                                    \

@@ -121,7 +121,11 @@ def test_decompress_large_roundtrip_property():
 @pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("mode,gs,n_groups", [("int4_sym", 24, 1365 * 2 + 7), ("int4_asym", 128, 4098),
                                               ("int8_asym", 14336, 5), ("int8_sym", 72, 1000), ("nf4", 40, 3001),
-                                              ("mxfp4", 32, 5000), ("int4_asym", 8, 70000)])
+                                              ("mxfp4", 32, 5000), ("int4_asym", 8, 70000),
+                                              # >= 8192 chunks of 256 vectors: four vectors per thread, ragged ends
+                                              ("nf4", 40, 420001), ("mxfp4", 32, 530003), ("int8_asym", 14336, 1201),
+                                              ("int4_asym", 128, 140003), ("int8_sym", 72, 240001),
+                                              ("int4_sym", 24, 700001)])
 def test_flat_decompress_group_indexing(mode, gs, n_groups, out_dtype):
     """The fp16 / E8M0 kernel finds a thread's group from a 2-D grid (spans of groups, a shift or a float multiply with
     one correction inside a span): group sizes that are not powers of two, a ragged last span, many spans -- against
