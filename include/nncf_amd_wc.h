@@ -337,6 +337,26 @@ int nncf_amd_gptq_block(const float* weight, float* quantized, float* err_block,
                         int32_t* zps, int use_given_params, void* stream);
 
 /*
+ * The dense products of GPTQ's algebra on the bf16 matrix cores (fp32 GEMMs in the reference: the trailing update
+ * W[:, i2:] -= Err @ Hinv[i1:i2, i2:] of gptq.py:363 and the products behind linalg.cholesky / cholesky_inverse of
+ * :283-285).  nncf_amd_split3_bf16 writes an fp32 matrix view as its exact three-way bf16 split x = h + m + l, six-fold
+ * along the contraction index, which becomes the ROW index of the result: order 0 (left operand) h h h m m l, order 1
+ * (right operand) h m l h m h.
+ *   contract_cols == 0: src [k, n] -> dst [6k, n] (row 6t + s = slot s of src row t);
+ *   contract_cols != 0: src [m, k] -> dst [6k, m] (row 6t + s = slot s of src column t);  negate != 0 splits -x.
+ *   src: fp32, row pitch src_pitch;  dst: bf16, row pitch dst_pitch (elements).
+ * nncf_amd_gemm_bf16_tn_acc: C[m, n] += P^T Q for bf16 P [t, m] (pitch ldp), Q [t, n] (pitch ldq), fp32 accumulation on
+ * the MFMA, one fp32 atomic add per element of C and split of t.  With the two splits of fp32 A [m, k] and B as P and Q
+ * (t = 6k) this is C += A B to fp32-GEMM accuracy (hh + hm + hl + mh + mm + lh: what is dropped is below 2^-24 |a||b|).
+ *   P, Q: 16-byte aligned, pitches multiples of 8, t * pitch * 2 < 2^32 each (else NNCF_AMD_ERR_UNSUPPORTED: the caller
+ *   keeps its fp32 GEMM);  C: fp32, row pitch ldc.
+ */
+int nncf_amd_split3_bf16(const float* src, int64_t rows, int64_t cols, int64_t src_pitch, int contract_cols, int order,
+                         int negate, void* dst, int64_t dst_pitch, void* stream);
+int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, int64_t ldp, const void* q, int64_t ldq, int64_t m,
+                              int64_t n, int64_t t, void* stream);
+
+/*
  * Inverse Cholesky factor of one small SPD block: linv = L^-1 (lower triangle written, the rest left untouched)
  * with a = L L^T; only the lower triangle of `a` is read.  Base case of the blocked factorization behind GPTQ's
  * `hessian_inv` (gptq.py:283-285: linalg.cholesky -> cholesky_inverse -> cholesky(upper=True), i.e. the

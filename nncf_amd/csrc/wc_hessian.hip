@@ -560,6 +560,256 @@ __global__ __launch_bounds__(256) void k_syrk16b(float* __restrict__ h, const Sy
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// C += P^T Q on the same tile engine (256x256 tiles, 4 waves of 128x128, 32-row stages by buffer DMA, transposing LDS
+// reads, written-out issue order): the dense products of GPTQ's algebra -- the far trailing update of gptq.py:363 and
+// the large products of the Hinv recursion behind :283-285, fp32 GEMMs in the reference -- with both operands given as
+// bf16 matrices whose ROWS are the contraction index: P [T, M] (row pitch ldp), Q [T, N] (row pitch ldq).  The caller
+// passes the six-fold three-way bf16 splits of the fp32 operands (k_split3_rows / k_split3_cols below; T = 6k), so the
+// sum over T is the fp32 product to fp32-GEMM accuracy.  One fp32 atomic add per element of C and token split (with
+// one split the result does not depend on any order).  Rows of P / Q past T read as zero through the buffer bounds
+// check; columns past M / N feed entries that are never written.
+struct Gemm16Args {
+    float* c;
+    const void* p;
+    const void* q;
+    uint32_t p_bytes, q_bytes;  // T * ldp * 2, T * ldq * 2  (< 2^32: checked by the host)
+    uint32_t ldp, ldq, ldc;     // elements
+    uint32_t M, N;
+    int tm, tn, stages, stages_per_split;
+};
+
+__global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
+    extern __shared__ __attribute__((aligned(1024))) char smem16[];  // [GST][A, B][GK * GROW]
+    // block -> (split, tile): XCD x takes the x-th contiguous eighth of the list; tiles go band by band (4 tile rows),
+    // column by column inside a band, so the blocks that share an L2 share panels
+    const uint32_t tiles = (uint32_t)(g.tm * g.tn), total = gridDim.x;
+    const uint32_t lin = blockIdx.x, xcd = lin & 7, nth = lin >> 3;
+    const uint32_t logical = xcd * (total >> 3) + (xcd < (total & 7) ? xcd : (total & 7)) + nth;
+    const int split = (int)(logical / tiles);
+    const uint32_t qid = logical % tiles;
+    const uint32_t band = qid / (4u * (uint32_t)g.tn), in_band = qid % (4u * (uint32_t)g.tn);
+    const int r0 = (int)band * 4, rows = g.tm - r0 < 4 ? g.tm - r0 : 4;
+    const int ti = r0 + (int)(in_band % (uint32_t)rows), tj = (int)(in_band / (uint32_t)rows);
+    const uint32_t i0 = (uint32_t)ti * GB, j0 = (uint32_t)tj * GB;
+    const int s_begin = split * g.stages_per_split;
+    const int s_end = s_begin + g.stages_per_split < g.stages ? s_begin + g.stages_per_split : g.stages;
+    if (s_begin >= s_end) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    i32x4 rsrc_p, rsrc_q;
+    {
+        const uintptr_t bp = (uintptr_t)g.p, bq = (uintptr_t)g.q;
+        rsrc_p[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)bp);
+        rsrc_p[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((bp >> 32) & 0xffffu));
+        rsrc_p[2] = __builtin_amdgcn_readfirstlane((int)g.p_bytes);
+        rsrc_p[3] = 0x00020000;
+        rsrc_q[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)bq);
+        rsrc_q[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((bq >> 32) & 0xffffu));
+        rsrc_q[2] = __builtin_amdgcn_readfirstlane((int)g.q_bytes);
+        rsrc_q[3] = 0x00020000;
+    }
+    // DMA: wave w brings rows 8w .. 8w+7 of a stage, two rows per instruction (chunk permutation as in k_syrk16b)
+    uint32_t voff_p[4], voff_q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t row = 8 * wave + 2 * u + (lane >> 5);
+        const uint32_t chunk = (uint32_t)((lane & 31) ^ ((row & 3) << 2)) * 16u;
+        voff_p[u] = row * g.ldp * 2u + chunk;
+        voff_q[u] = row * g.ldq * 2u + chunk;
+    }
+    const int nst = s_end - s_begin;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem16;
+    uint32_t dma_dst = 0, so_p = 0, so_q = 0;
+    auto issue_prepare = [&](int st) {
+        dma_dst = lds_base + (uint32_t)((st % GST) * (2 * GK * GROW) + 8 * wave * GROW);
+        const uint32_t gst = (uint32_t)(s_begin + st);
+        so_p = gst * GK * g.ldp * 2u + i0 * 2u;
+        so_q = gst * GK * g.ldq * 2u + j0 * 2u;
+    };
+    auto issue_one = [&](int u) {
+        if (u < 4) buffer_dma16(rsrc_p, voff_p[u], so_p, dma_dst + u * 2 * GROW);
+        else buffer_dma16(rsrc_q, voff_q[u - 4], so_q, dma_dst + GK * GROW + (u - 4) * 2 * GROW);
+    };
+    auto issue = [&](int st) {
+        issue_prepare(st);
+        for (int u = 0; u < 8; ++u) issue_one(u);
+    };
+    const int kh = lane >> 5, grp = (lane >> 4) & 1, i16 = lane & 15, r3 = i16 >> 2;
+    const uint32_t lane_const = (uint32_t)(8 * kh + r3) * GROW + (uint32_t)(grp * 2 + ((i16 & 3) >> 1)) * 16u + (uint32_t)(i16 & 1) * 8u;
+    uint32_t offa[4], offb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        offa[m] = lane_const + (uint32_t)(wi * 16 + ((m ^ r3) << 2)) * 16u;
+        offb[m] = lane_const + (uint32_t)(wj * 16 + ((m ^ r3) << 2)) * 16u + (uint32_t)(GK * GROW);
+    }
+    typedef int op_t __attribute__((ext_vector_type(4)));
+    auto read_op = [&](const char* img, uint32_t off, int ks) {
+        struct Pair {
+            s16x4 lo, hi;
+        } pr;
+        pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + off + (16 * ks) * GROW));
+        pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + off + (16 * ks + 4) * GROW));
+        return __builtin_bit_cast(op_t, pr);
+    };
+    auto mfma = [&](f32x16& c, const op_t& a, const op_t& b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
+    };
+    auto wait_dma = [&](int outstanding) {
+        switch (outstanding) {
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    constexpr int kBarrierAfter = 7;
+    constexpr int kDmaSlots = 16 - (kBarrierAfter + 1) + 16;
+    constexpr int NDMA = 8;
+    op_t a0[4], b0[4], a1[4], b1[4];
+    // one k-step (16 rows) of 16 MFMAs; see k_syrk16b for the interleaving of reads, the barrier and the DMA issue
+    auto kstep = [&](const op_t* ca, const op_t* cb, op_t* na, op_t* nb, const char* img, int ks, auto reads, auto sync,
+                     auto dma, auto slot0, auto steady, int outstanding) {
+        constexpr bool READS = decltype(reads)::value, SYNC = decltype(sync)::value, STEADY = decltype(steady)::value;
+        constexpr bool DMA = decltype(dma)::value;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            mfma(acc[i >> 2][i & 3], ca[i >> 2], cb[i & 3]);
+            if constexpr (READS) {
+                if (i < 4) na[i] = read_op(img, offa[i], ks);
+                else if (i < 8) nb[i - 4] = read_op(img, offb[i - 4], ks);
+            }
+            if constexpr (SYNC) {
+                if (i == kBarrierAfter) {
+                    if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // NDMA * (GST - 3)
+                    else wait_dma(outstanding);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            if constexpr (DMA) {
+                constexpr int SLOT0 = decltype(slot0)::value;
+                const int slot = SLOT0 + i;
+                if (slot >= 0 && slot < kDmaSlots && slot % (kDmaSlots / NDMA) == 0) issue_one(slot / (kDmaSlots / NDMA));
+            }
+        }
+    };
+    static_assert(GST == 4, "vmcnt(8) above = one stage of lookahead behind the one waited for");
+    using T = std::true_type;
+    using F = std::false_type;
+    for (int st = 0; st < GST - 1 && st < nst; ++st) issue(st);
+    wait_dma((nst - 1 < GST - 2 ? nst - 1 : GST - 2) * NDMA);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        a0[m] = read_op(smem16, offa[m], 0);
+        b0[m] = read_op(smem16, offb[m], 0);
+    }
+    {
+        int st = 0;
+        for (; st + GST - 1 < nst; ++st) {
+            const char* img = smem16 + (st % GST) * (2 * GK * GROW);
+            issue_prepare(st + GST - 1);
+            kstep(a0, b0, a1, b1, img, 1, T{}, T{}, T{}, std::integral_constant<int, -(kBarrierAfter + 1)>{}, T{}, 0);
+            kstep(a1, b1, a0, b0, smem16 + ((st + 1) % GST) * (2 * GK * GROW), 0, T{}, F{}, T{}, std::integral_constant<int, 16 - (kBarrierAfter + 1)>{}, T{}, 0);
+        }
+        for (; st + 1 < nst; ++st) {
+            const char* img = smem16 + (st % GST) * (2 * GK * GROW);
+            kstep(a0, b0, a1, b1, img, 1, T{}, T{}, F{}, std::integral_constant<int, 0>{}, F{}, (nst - 2 - st) * NDMA);
+            kstep(a1, b1, a0, b0, smem16 + ((st + 1) % GST) * (2 * GK * GROW), 0, T{}, F{}, F{}, std::integral_constant<int, 0>{}, F{}, 0);
+        }
+        const char* img = smem16 + (st % GST) * (2 * GK * GROW);
+        kstep(a0, b0, a1, b1, img, 1, T{}, F{}, F{}, std::integral_constant<int, 0>{}, F{}, 0);
+        kstep(a1, b1, a0, b0, img, 0, F{}, F{}, F{}, std::integral_constant<int, 0>{}, F{}, 0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    const uint32_t kl = lane >> 5, cl = lane & 31;
+    const uint32_t bi = i0 + wi * 128 + 4 * kl, bj = j0 + wj * 128 + cl;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t gj = bj + n * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t gi = bi + m * 32 + (r & 3) + 8 * (r >> 2);
+                if (gi < g.M && gj < g.N) atomicAdd(g.c + ((uint64_t)gi * g.ldc + gj), acc[m][n][r]);
+            }
+        }
+}
+
+// The six-fold three-way bf16 split of an fp32 matrix view, rows of the result = contraction index (what k_gemm16t
+// reads).  x = h + m + l exactly (8 + 8 + 8 significand bits, truncating); the six slots hold, for a left operand
+// (order 0) h h h m m l, for a right operand (order 1) h m l h m h, so that the sum over the slots is
+// hh + hm + hl + mh + mm + lh: everything of the fp32 product above 2^-24 |a||b|.
+//   k_split3_rows: src [k, n] (contraction = rows)    -> dst [6k, n], row 6t + s = slot s of src row t
+//   k_split3_cols: src [m, k] (contraction = columns) -> dst [6k, m], row 6t + s = slot s of src column t (transposed
+//                  through LDS: reads and writes are both row-contiguous)
+// (slot-minor rows: a bound on the contraction index t is a bound on the rows, i.e. on the stages a tile walks)
+__device__ __forceinline__ void split3_of(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+    const uint32_t hb = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, hb);
+    const uint32_t mb = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, mb);
+    h = hb >> 16, m = mb >> 16, l = __builtin_bit_cast(uint32_t, r2) >> 16;
+}
+__device__ __forceinline__ int split3_slot_piece(int order, int s) {
+    return order == 0 ? (s < 3 ? 0 : (s < 5 ? 1 : 2)) : (s < 3 ? s : (s < 5 ? s - 3 : 0));
+}
+
+__global__ __launch_bounds__(256) void k_split3_rows(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t src_pitch,
+                                                     int order, float sign, uint16_t* __restrict__ dst, int64_t dst_pitch) {
+    const int64_t vpr = (cols + 3) / 4;
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= rows * vpr) return;
+    const int64_t r = v / vpr, c = (v % vpr) * 4;
+    const int nc = cols - c < 4 ? (int)(cols - c) : 4;
+    uint32_t piece[3][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = i < nc ? src[r * src_pitch + c + i] * sign : 0.0f;
+        split3_of(x, piece[0][i], piece[1][i], piece[2][i]);
+    }
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int p = split3_slot_piece(order, s);
+        uint16_t* out = dst + (r * 6 + s) * dst_pitch + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nc) out[i] = (uint16_t)(p == 0 ? piece[0][i] : (p == 1 ? piece[1][i] : piece[2][i]));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_split3_cols(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t src_pitch,
+                                                     int order, float sign, uint16_t* __restrict__ dst, int64_t dst_pitch) {
+    __shared__ float t[64][65];
+    const int64_t tiles_c = (cols + 63) / 64;
+    const int64_t r0 = (int64_t)(blockIdx.x / tiles_c) * 64, c0 = (int64_t)(blockIdx.x % tiles_c) * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int rr = ly; rr < 64; rr += 4) {
+        const int64_t gr = r0 + rr, gc = c0 + lx;
+        t[rr][lx] = (gr < rows && gc < cols) ? src[gr * src_pitch + gc] * sign : 0.0f;
+    }
+    __syncthreads();
+    // thread (lx, ly): source column c0 + cc (a row of dst), source row r0 + lx (a column of dst)
+    for (int cc = ly; cc < 64; cc += 4) {
+        const int64_t gc = c0 + cc, gr = r0 + lx;
+        if (gc >= cols || gr >= rows) continue;
+        uint32_t pc[3];
+        split3_of(t[lx][cc], pc[0], pc[1], pc[2]);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) dst[(gc * 6 + s) * dst_pitch + gr] = (uint16_t)pc[split3_slot_piece(order, s)];
+    }
+}
+
 // H[j][i] = H[i][j] for i < j: the SYRK kernels accumulate the upper triangle only, so H comes out exactly
 // symmetric whatever the order of the atomic partial sums.  64x64 tiles transposed through LDS: reads and writes
 // are row-contiguous.
@@ -789,4 +1039,86 @@ static int hessian_accumulate_impl(float* h, const void* x, int x_dtype, int64_t
     int st32 = launch_status("hessian_syrk");
     if (st32 != NNCF_AMD_OK) return st32;
     return do_mirror ? mirror(h, k, s) : NNCF_AMD_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int nncf_amd_split3_bf16(const float* src, int64_t rows, int64_t cols, int64_t src_pitch, int contract_cols,
+                                    int order, int negate, void* dst, int64_t dst_pitch, void* stream) {
+    using namespace wc;
+    if (rows < 0 || cols < 0 || src_pitch < cols || (order != 0 && order != 1) || dst_pitch < (contract_cols ? rows : cols)) {
+        set_error("split3_bf16: bad argument");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (rows == 0 || cols == 0) return NNCF_AMD_OK;
+    if (!src || !dst) {
+        set_error("split3_bf16: NULL buffer");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const float sign = negate ? -1.0f : 1.0f;
+    if (contract_cols) {
+        const int64_t blocks = ((rows + 63) / 64) * ((cols + 63) / 64);
+        if (blocks > 0x7fffffffLL) {
+            set_error("split3_bf16: matrix too large for one launch");
+            return NNCF_AMD_ERR_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL(k_split3_cols, dim3((unsigned)blocks), dim3(256), 0, s, src, rows, cols, src_pitch, order, sign,
+                           (uint16_t*)dst, dst_pitch);
+    } else {
+        const int64_t vecs = rows * ((cols + 3) / 4);
+        if ((vecs + 255) / 256 > 0x7fffffffLL) {
+            set_error("split3_bf16: matrix too large for one launch");
+            return NNCF_AMD_ERR_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s, src, rows, cols, src_pitch,
+                           order, sign, (uint16_t*)dst, dst_pitch);
+    }
+    return launch_status("split3_bf16");
+}
+
+extern "C" int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, int64_t ldp, const void* q, int64_t ldq,
+                                         int64_t m, int64_t n, int64_t t, void* stream) {
+    using namespace wc;
+    if (m < 0 || n < 0 || t < 0 || ldc < n || ldp < m || ldq < n) {
+        set_error("gemm_bf16_tn_acc: bad argument");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    if (m == 0 || n == 0 || t == 0) return NNCF_AMD_OK;
+    if (!c || !p || !q) {
+        set_error("gemm_bf16_tn_acc: NULL buffer");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
+    // the DMA reads 16-byte chunks at 32-bit offsets inside each operand
+    if (ldp % 8 != 0 || ldq % 8 != 0 || ((uintptr_t)p & 15u) || ((uintptr_t)q & 15u) || (uint64_t)t * ldp * 2 >= (1ull << 32) ||
+        (uint64_t)t * ldq * 2 >= (1ull << 32) || m >= (1ll << 31) || n >= (1ll << 31) || ldc >= (1ll << 32)) {
+        set_error("gemm_bf16_tn_acc: operands must be 16-byte aligned with row pitches in multiples of 8 and below 4 GiB each");
+        return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+    const int tm = (int)((m + GB - 1) / GB), tn = (int)((n + GB - 1) / GB);
+    const int64_t tiles = (int64_t)tm * tn;
+    const int64_t stages = (t + GK - 1) / GK;
+    // >= 2 rounds of blocks over the 256 CUs where the contraction is long enough to split (>= 64 stages per block)
+    int64_t sp = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+    const int64_t maxsp = (stages + 63) / 64;
+    if (sp > maxsp) sp = maxsp;
+    if (sp < 1) sp = 1;
+    const int64_t sps = (stages + sp - 1) / sp;
+    sp = (stages + sps - 1) / sps;
+    if (tiles * sp > 0x7fffffffLL) {
+        set_error("gemm_bf16_tn_acc: too many tiles");
+        return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+    constexpr size_t lds_bytes = (size_t)GST * 2 * GK * GROW;
+    static OncePerDevice attr_once;
+    if (attr_once.first_on_device() != 0) {
+        if (hipFuncSetAttribute((const void*)k_gemm16t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+            attr_once.forget_current();
+            return launch_status("gemm_bf16_tn_acc attribute");
+        }
+    }
+    Gemm16Args g = {c, p, q, (uint32_t)((uint64_t)t * ldp * 2), (uint32_t)((uint64_t)t * ldq * 2), (uint32_t)ldp, (uint32_t)ldq,
+                    (uint32_t)ldc, (uint32_t)m, (uint32_t)n, tm, tn, (int)stages, (int)sps};
+    hipLaunchKernelGGL(k_gemm16t, dim3((unsigned)(tiles * sp)), dim3(256), lds_bytes, (hipStream_t)stream, g);
+    return launch_status("gemm_bf16_tn_acc");
 }

@@ -212,7 +212,7 @@ def quantize_weights(hessian: torch.Tensor, weight: torch.Tensor, config: Weight
                 if errs is not None:
                     errs[:, i1 - s1:i2 - s1] = err
             if errs is not None:
-                W[:, near_end:].addmm_(errs, hinv[s1:s2, near_end:], alpha=-1.0)
+                _mm(W[:, near_end:], errs, hinv[s1:s2, near_end:], acc=W[:, near_end:], negate=True)
     out_scales = scales.reshape(N, ngroups, 1)
     out_zps = zps.reshape(N, ngroups, 1) if asym else None
     if config.group_size == -1:
@@ -398,6 +398,50 @@ CHOLINV_BASE = 128  # blocks up to this size go to nncf_amd_cholinv_block (one w
 
 TRI_SPLIT_MIN = 1024  # triangular-aware products split down to this size (measured: 306 -> 231 ms at K = 28672)
 
+BF16X3_MIN_FLOPS = 3e10  # products from this size on run on the bf16 matrix cores (six-fold three-way split operands)
+
+
+def _split3(x: torch.Tensor, contract_cols: bool, order: int, negate: bool = False) -> torch.Tensor:
+    """nncf_amd_split3_bf16: the exact three-way bf16 split of an fp32 matrix view, six-fold along the contraction
+    index (order 0: left operand, order 1: right operand), rows of the result = contraction index."""
+    r, c = x.shape
+    k, w = (c, r) if contract_cols else (r, c)
+    dst = torch.empty((6 * k, w), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().nncf_amd_split3_bf16(_lib.ptr(x), r, c, x.stride(0), int(contract_cols), order, int(negate),
+                                               _lib.ptr(dst), w, _lib.stream_of(x)))
+    return dst
+
+
+def _mm(out: torch.Tensor, A: torch.Tensor, B: torch.Tensor, b_t: bool = False, acc: Optional[torch.Tensor] = None,
+        negate: bool = False) -> torch.Tensor:
+    """out = (acc | 0) +- A @ (B^T if b_t else B), fp32 in and out (`acc` may be `out`).  Large products run on the
+    bf16 MFMA: both operands as their exact three-way bf16 split, six-fold along the contraction (k_split3_*), then
+    ONE hand-written GEMM over the 6x longer contraction with fp32 accumulation (k_gemm16t, the Hessian kernel's tile
+    engine; csrc/wc_hessian.hip) -- the six leading products of the fp32 product, as accurate as the fp32 GEMM
+    (measured 5e-7..9e-6 against 4e-7..5e-6 of max|C|), at 1.17-1.32 PFLOP/s = 170-205 TFLOP/s of fp32 work where the
+    library's fp32 GEMM does 119-153: far trailing update 8192 x 1024 x 27648 3.51 -> 2.44 ms incl. the splits, X T^T
+    at n = 14336 38.6 -> 29.6 ms, n = 3584 0.77 -> 0.65 ms.  Smaller or unaligned products keep the fp32 GEMM."""
+    m, k = A.shape
+    n = B.shape[0] if b_t else B.shape[1]
+    if (A.is_cuda and 2.0 * m * k * n >= BF16X3_MIN_FLOPS and m % 8 == 0 and n % 8 == 0 and 12 * k * max(m, n) < 2 ** 32
+            and A.dtype == B.dtype == out.dtype == torch.float32 and A.stride(1) == 1 and B.stride(1) == 1
+            and out.stride(1) == 1):
+        with torch.cuda.device(A.device):
+            p6 = _split3(A, True, 0, negate)
+            q6 = _split3(B, b_t, 1)
+            if acc is None:
+                out.zero_()
+            elif acc is not out and (acc.data_ptr() != out.data_ptr() or acc.stride() != out.stride()):
+                out.copy_(acc)
+            _lib.check(_lib.lib().nncf_amd_gemm_bf16_tn_acc(_lib.ptr(out), out.stride(0), _lib.ptr(p6), m, _lib.ptr(q6), n,
+                                                            m, n, 6 * k, _lib.stream_of(out)))
+        return out
+    Bm = B.T if b_t else B
+    if acc is None:
+        torch.matmul(A, Bm, out=out)
+        return out.neg_() if negate else out
+    return torch.addmm(acc, A, Bm, beta=1.0, alpha=-1.0 if negate else 1.0, out=out)
+
 
 def _mm_dense_lowerT(X: torch.Tensor, T: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """X @ T^T for lower-triangular T, skipping T's zero block: with T = [[T11, 0], [T21, T22]],
@@ -406,11 +450,11 @@ def _mm_dense_lowerT(X: torch.Tensor, T: torch.Tensor, out: Optional[torch.Tenso
     if out is None:
         out = torch.empty((X.shape[0], n), dtype=X.dtype, device=X.device)
     if n < TRI_SPLIT_MIN:
-        return torch.matmul(X, T.T, out=out)
+        return _mm(out, X, T, b_t=True)
     h = ((n // 2 + 127) // 128) * 128
     _mm_dense_lowerT(X[:, :h], T[:h, :h], out[:, :h])
     _mm_dense_lowerT(X[:, h:], T[h:, h:], out[:, h:])
-    out[:, h:].addmm_(X[:, :h], T[h:, :h].T)
+    _mm(out[:, h:], X[:, :h], T[h:, :h], b_t=True, acc=out[:, h:])
     return out
 
 
@@ -420,11 +464,11 @@ def _mm_dense_lower(X: torch.Tensor, T: torch.Tensor, out: Optional[torch.Tensor
     if out is None:
         out = torch.empty((X.shape[0], n), dtype=X.dtype, device=X.device)
     if n < TRI_SPLIT_MIN:
-        return torch.matmul(X, T, out=out)
+        return _mm(out, X, T)
     h = ((n // 2 + 127) // 128) * 128
     _mm_dense_lower(X[:, :h], T[:h, :h], out[:, :h])
     _mm_dense_lower(X[:, h:], T[h:, h:], out[:, h:])
-    out[:, :h].addmm_(X[:, h:], T[h:, :h])
+    _mm(out[:, :h], X[:, h:], T[h:, :h], acc=out[:, :h])
     return out
 
 
@@ -432,11 +476,11 @@ def _mm_lower_dense(T: torch.Tensor, X: torch.Tensor, out: torch.Tensor) -> torc
     """T @ X for lower-triangular T: [[T11 X1], [T21 X1 + T22 X2]]."""
     n = T.shape[0]
     if n < TRI_SPLIT_MIN:
-        return torch.matmul(T, X, out=out)
+        return _mm(out, T, X)
     h = ((n // 2 + 127) // 128) * 128
     _mm_lower_dense(T[:h, :h], X[:h], out[:h])
     _mm_lower_dense(T[h:, h:], X[h:], out[h:])
-    out[h:].addmm_(T[h:, :h], X[:h])
+    _mm(out[h:], T[h:, :h], X[:h], acc=out[h:])
     return out
 
 
@@ -449,12 +493,12 @@ def _syrk_lower_sub(C: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
     def rec(S, C, A):
         m = C.shape[0]
         if m < TRI_SPLIT_MIN:
-            torch.addmm(C, A, A.T, beta=1.0, alpha=-1.0, out=S)
+            _mm(S, A, A, b_t=True, acc=C, negate=True)
             return
         h = ((m // 2 + 127) // 128) * 128
         rec(S[:h, :h], C[:h, :h], A[:h])
         rec(S[h:, h:], C[h:, h:], A[h:])
-        torch.addmm(C[h:, :h], A[h:], A[:h].T, beta=1.0, alpha=-1.0, out=S[h:, :h])
+        _mm(S[h:, :h], A[h:], A[:h], b_t=True, acc=C[h:, :h], negate=True)
 
     rec(S, C, A)
     return S

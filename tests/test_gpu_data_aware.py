@@ -691,3 +691,100 @@ def test_awq_preparation_helpers_equal_the_torch_ops():
             assert got.shape == want.shape and torch.equal(got, want), (n, q)
     s = torch.rand((2, 500), device="cuda", generator=g).round(decimals=2)  # many equal keys: stable order matters
     assert torch.equal(torch.sort(-s, dim=-1, stable=True)[1], torch.argsort(-s, stable=True))
+
+
+# ---- the bf16 split GEMM behind the large products of GPTQ's dense algebra (csrc/wc_hessian.hip: k_split3_*, k_gemm16t)
+def _split3_call(x, contract_cols, order, negate=False):
+    from nncf_amd import gptq
+    return gptq._split3(x, contract_cols, order, negate)
+
+
+@pytest.mark.parametrize("contract_cols", [False, True])
+@pytest.mark.parametrize("order", [0, 1])
+def test_split3_is_the_exact_three_way_split(contract_cols, order):
+    """x = h + m + l exactly with 8-bit pieces; row 6t + s of the result holds slot s (order 0: h h h m m l, order 1:
+    h m l h m h) of contraction index t; views with a row pitch, ragged sizes, negation."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.randn(301, 530, device="cuda", generator=g) * torch.exp(4 * torch.randn(301, 530, device="cuda", generator=g))
+    base[3, 7] = 0.0
+    base[5, 9] = 1e-41  # subnormal
+    x = base[:, 3:523]  # pitch 530, first column not 16-byte aligned
+    d = _split3_call(x, contract_cols, order, negate=bool(order)).float()
+    src = (x.T if contract_cols else x) * (-1.0 if order else 1.0)
+    k = src.shape[0]
+    h = (src.contiguous().view(torch.int32) & -65536).view(torch.float32)
+    r1 = src - h
+    m = (r1.view(torch.int32) & -65536).view(torch.float32)
+    l = ((r1 - m).view(torch.int32) & -65536).view(torch.float32)  # (a cut only below 2^-133: subnormal inputs)
+    normal = src.abs() > 1e-30
+    assert torch.equal((h + m + l)[normal], src[normal])
+    assert float((h + m + l - src).abs().max()) < 1e-39
+    want = [h, h, h, m, m, l] if order == 0 else [h, m, l, h, m, h]
+    pieces = d.reshape(k, 6, -1)
+    for s in range(6):
+        assert torch.equal(pieces[:, s], want[s]), s
+
+
+@pytest.mark.parametrize("m,k,n", [(256, 32, 256), (264, 40, 520), (1000, 136, 776), (512, 2048, 512), (8, 3, 8),
+                                   (2048, 1024, 4096)])
+def test_gemm_bf16_tn_acc_matches_float64(m, k, n):
+    """C -= A B through the split + k_gemm16t against float64 (as close as the fp32 GEMM: 2e-6 of max|C|), on a strided
+    view of C, with ragged tiles and token splits."""
+    from nncf_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(m + k + n)
+    A = torch.randn(m, k, device="cuda", generator=g)
+    B = torch.randn(k, n + 8, device="cuda", generator=g)[:, 8:]
+    Cfull = torch.randn(m, n + 16, device="cuda", generator=g)
+    C = Cfull[:, 16:]
+    ref = C.double() - A.double() @ B.double()
+    guard = Cfull[:, :16].clone()
+    P = _split3_call(A, True, 0, negate=True)
+    Q = _split3_call(B, False, 1)
+    _lib.check(_lib.lib().nncf_amd_gemm_bf16_tn_acc(_lib.ptr(C), C.stride(0), _lib.ptr(P), m, _lib.ptr(Q), n, m, n, 6 * k,
+                                                    _lib.stream_of(C)))
+    err = float((C.double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    assert torch.equal(Cfull[:, :16], guard)  # nothing outside the view is written
+    # B given transposed ([n, k]: contraction over its columns) gives the same sums
+    C2 = torch.zeros(m, n, device="cuda")
+    Q2 = _split3_call(B.T.contiguous(), True, 1)
+    assert torch.equal(Q2, Q)
+    _lib.check(_lib.lib().nncf_amd_gemm_bf16_tn_acc(_lib.ptr(C2), n, _lib.ptr(P), m, _lib.ptr(Q2), n, m, n, 6 * k,
+                                                    _lib.stream_of(C2)))
+    ref2 = -(A.double() @ B.double())
+    assert float((C2.double() - ref2).abs().max() / ref2.abs().max()) < 2e-6
+
+
+def test_gemm_bf16_tn_acc_rejects_what_it_cannot_address():
+    from nncf_amd import _lib
+    L = _lib.lib()
+    c = torch.zeros(8, 8, device="cuda")
+    p = torch.zeros(6, 8, dtype=torch.bfloat16, device="cuda")
+    assert L.nncf_amd_gemm_bf16_tn_acc(_lib.ptr(c), 8, _lib.ptr(p), 4, _lib.ptr(p), 8, 8, 8, 6, None) == _lib.ERR_BAD_ARG  # ldp < m
+    assert L.nncf_amd_gemm_bf16_tn_acc(_lib.ptr(c), 8, _lib.ptr(p), 12, _lib.ptr(p), 8, 8, 8, 6, None) == _lib.ERR_UNSUPPORTED  # pitch % 8
+    assert L.nncf_amd_gemm_bf16_tn_acc(_lib.ptr(c), 8, _lib.ptr(p), 8, _lib.ptr(p), 8, 8, 8, 1 << 29, None) == _lib.ERR_UNSUPPORTED  # >= 4 GiB
+
+
+def test_mm_takes_the_same_decision_for_both_routes():
+    """gptq._mm: large aligned products on the bf16 route, the rest on the fp32 GEMM; both within fp32-GEMM accuracy of
+    float64, for every combination the recursion uses (B transposed or not, accumulate into out or a copy, negated)."""
+    from nncf_amd import gptq
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (m, k, n) in ((3072, 2048, 3072), (200, 64, 120)):  # 3.9e10 flops: bf16 route; tiny: fp32 GEMM
+        A = torch.randn(m, k, device="cuda", generator=g)
+        for b_t in (False, True):
+            B = torch.randn((n, k) if b_t else (k, n), device="cuda", generator=g)
+            prod = A.double() @ (B.double().T if b_t else B.double())
+            for negate in (False, True):
+                sgn = -1.0 if negate else 1.0
+                out = torch.empty(m, n, device="cuda")
+                gptq._mm(out, A, B, b_t=b_t, negate=negate)
+                assert float((out.double() - sgn * prod).abs().max() / prod.abs().max()) < 4e-6
+                C = torch.randn(m, n, device="cuda", generator=g)
+                ref = C.double() + sgn * prod
+                out2 = C.clone()
+                gptq._mm(out2, A, B, b_t=b_t, acc=out2, negate=negate)
+                assert float((out2.double() - ref).abs().max() / ref.abs().max()) < 4e-6
+                out3 = torch.empty(m, n, device="cuda")
+                gptq._mm(out3, A, B, b_t=b_t, acc=C, negate=negate)
+                assert float((out3.double() - ref).abs().max() / ref.abs().max()) < 4e-6
