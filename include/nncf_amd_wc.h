@@ -350,11 +350,16 @@ int nncf_amd_gptq_block(const float* weight, float* quantized, float* err_block,
  * (t = 6k) this is C += A B to fp32-GEMM accuracy (hh + hm + hl + mh + mm + lh: what is dropped is below 2^-24 |a||b|).
  *   P, Q: 16-byte aligned, pitches multiples of 8, t * pitch * 2 < 2^32 each (else NNCF_AMD_ERR_UNSUPPORTED: the caller
  *   keeps its fp32 GEMM);  C: fp32, row pitch ldc.
+ *   tri: what the kernel may skip for a triangular operand or result (contraction index = row / 6 of P and Q), at the
+ *   granularity of its 256-wide tiles -- 0 nothing;  1: C = A T^T with T lower triangular (only contraction indices <=
+ *   the column of C contribute);  2: C = A T with T lower triangular (indices >= the column of C);  3: C = T B with T
+ *   lower triangular (indices <= the row of C);  4: only the lower triangle of C is wanted (tiles strictly above the
+ *   diagonal are not touched).  The skipped terms must be zeros (1-3) or unread by the caller (4).
  */
 int nncf_amd_split3_bf16(const float* src, int64_t rows, int64_t cols, int64_t src_pitch, int contract_cols, int order,
                          int negate, void* dst, int64_t dst_pitch, void* stream);
 int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, int64_t ldp, const void* q, int64_t ldq, int64_t m,
-                              int64_t n, int64_t t, void* stream);
+                              int64_t n, int64_t t, int tri, void* stream);
 
 /*
  * Inverse Cholesky factor of one small SPD block: linv = L^-1 (lower triangle written, the rest left untouched)

@@ -79,7 +79,7 @@ SIGNATURES = {
                                     c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "nncf_amd_split3_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "nncf_amd_gemm_bf16_tn_acc": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
-                                          c_void_p]),
+                                          c_int, c_void_p]),
     "nncf_amd_cholinv_block": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "nncf_amd_gptq_pack8": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     "nncf_amd_gptq_dequant8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p]),

@@ -576,24 +576,48 @@ struct Gemm16Args {
     uint32_t p_bytes, q_bytes;  // T * ldp * 2, T * ldq * 2  (< 2^32: checked by the host)
     uint32_t ldp, ldq, ldc;     // elements
     uint32_t M, N;
-    int tm, tn, stages, stages_per_split;
+    int tm, tn, stages, splits;
+    int tri;  // which stages / tiles can contribute (a triangular operand or result), see nncf_amd_gemm_bf16_tn_acc
 };
 
 __global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
     extern __shared__ __attribute__((aligned(1024))) char smem16[];  // [GST][A, B][GK * GROW]
-    // block -> (split, tile): XCD x takes the x-th contiguous eighth of the list; tiles go band by band (4 tile rows),
-    // column by column inside a band, so the blocks that share an L2 share panels
+    // block -> (split, tile): XCD x takes the x-th contiguous eighth of the list; tiles go band by band (4 tile lines),
+    // line by line inside a band, so the blocks that share an L2 share panels.  A triangular product's work per tile
+    // changes along one axis: the bands run ACROSS that axis (every band then has the same work), and both the bands
+    // and the positions inside a band are taken alternately from the two ends (0, last, 1, last - 1, ...), so that any
+    // contiguous run of the list -- an XCD's eighth, the tail of the launch -- mixes light and heavy tiles.
     const uint32_t tiles = (uint32_t)(g.tm * g.tn), total = gridDim.x;
     const uint32_t lin = blockIdx.x, xcd = lin & 7, nth = lin >> 3;
     const uint32_t logical = xcd * (total >> 3) + (xcd < (total & 7) ? xcd : (total & 7)) + nth;
     const int split = (int)(logical / tiles);
     const uint32_t qid = logical % tiles;
-    const uint32_t band = qid / (4u * (uint32_t)g.tn), in_band = qid % (4u * (uint32_t)g.tn);
-    const int r0 = (int)band * 4, rows = g.tm - r0 < 4 ? g.tm - r0 : 4;
-    const int ti = r0 + (int)(in_band % (uint32_t)rows), tj = (int)(in_band / (uint32_t)rows);
+    const bool across_cols = g.tri == 3 || g.tri == 4;  // work changes with the row of C: bands of tile columns
+    const uint32_t outer_n = (uint32_t)(across_cols ? g.tn : g.tm), inner_n = (uint32_t)(across_cols ? g.tm : g.tn);
+    const uint32_t nb = (outer_n + 3) / 4, rs = outer_n - 4 * (nb - 1), full = 4 * inner_n, shrt = rs * inner_n;
+    uint32_t seq, in_band;  // the short band (the last one) sits at position 1 of the alternating order
+    if (nb == 1 || qid < full) seq = 0, in_band = qid;
+    else if (qid < full + shrt) seq = 1, in_band = qid - full;
+    else seq = 2 + (qid - full - shrt) / full, in_band = (qid - full - shrt) % full;
+    const uint32_t band = (seq & 1) ? nb - 1 - (seq >> 1) : (seq >> 1);
+    const uint32_t lines = band == nb - 1 ? rs : 4;
+    const uint32_t line = band * 4 + in_band % lines, qc = in_band / lines;
+    const uint32_t inner = (qc & 1) ? inner_n - 1 - (qc >> 1) : (qc >> 1);
+    const int ti = (int)(across_cols ? inner : line), tj = (int)(across_cols ? line : inner);
     const uint32_t i0 = (uint32_t)ti * GB, j0 = (uint32_t)tj * GB;
-    const int s_begin = split * g.stages_per_split;
-    const int s_end = s_begin + g.stages_per_split < g.stages ? s_begin + g.stages_per_split : g.stages;
+    // the stages of this tile that can contribute: contraction index t = row / 6 of P and Q (slot-minor rows), so a
+    // 256-wide tile of a triangular operand bounds the rows at a multiple of 6 * 256 = 48 stages
+    constexpr int kStagesPerTile = 6 * GB / GK;
+    int lo = 0, hi = g.stages;
+    if (g.tri == 1) hi = (tj + 1) * kStagesPerTile;        // Q^T lower triangular: t <= column of C
+    else if (g.tri == 2) lo = tj * kStagesPerTile;         // Q lower triangular:   t >= column of C
+    else if (g.tri == 3) hi = (ti + 1) * kStagesPerTile;   // P^T lower triangular: t <= row of C
+    else if (g.tri == 4 && tj > ti) return;                // only the lower triangle of C is wanted
+    if (hi > g.stages) hi = g.stages;
+    if (lo >= hi) return;
+    // every tile's own range in `splits` equal parts
+    const int s_begin = lo + (int)((int64_t)(hi - lo) * split / g.splits);
+    const int s_end = lo + (int)((int64_t)(hi - lo) * (split + 1) / g.splits);
     if (s_begin >= s_end) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1078,9 +1102,9 @@ extern "C" int nncf_amd_split3_bf16(const float* src, int64_t rows, int64_t cols
 }
 
 extern "C" int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, int64_t ldp, const void* q, int64_t ldq,
-                                         int64_t m, int64_t n, int64_t t, void* stream) {
+                                         int64_t m, int64_t n, int64_t t, int tri, void* stream) {
     using namespace wc;
-    if (m < 0 || n < 0 || t < 0 || ldc < n || ldp < m || ldq < n) {
+    if (m < 0 || n < 0 || t < 0 || ldc < n || ldp < m || ldq < n || tri < 0 || tri > 4) {
         set_error("gemm_bf16_tn_acc: bad argument");
         return NNCF_AMD_ERR_BAD_ARG;
     }
@@ -1098,13 +1122,13 @@ extern "C" int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, i
     const int tm = (int)((m + GB - 1) / GB), tn = (int)((n + GB - 1) / GB);
     const int64_t tiles = (int64_t)tm * tn;
     const int64_t stages = (t + GK - 1) / GK;
-    // >= 2 rounds of blocks over the 256 CUs where the contraction is long enough to split (>= 64 stages per block)
-    int64_t sp = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+    // >= 2 rounds of blocks over the 256 CUs where the contraction is long enough to split (>= 64 stages per block on
+    // average; a triangular product has about half the tile x stage work of the full one)
+    const int64_t work_tiles = tri == 0 ? tiles : (tiles + 1) / 2;
+    int64_t sp = work_tiles >= 512 ? 1 : (512 + work_tiles - 1) / work_tiles;
     const int64_t maxsp = (stages + 63) / 64;
     if (sp > maxsp) sp = maxsp;
     if (sp < 1) sp = 1;
-    const int64_t sps = (stages + sp - 1) / sp;
-    sp = (stages + sps - 1) / sps;
     if (tiles * sp > 0x7fffffffLL) {
         set_error("gemm_bf16_tn_acc: too many tiles");
         return NNCF_AMD_ERR_UNSUPPORTED;
@@ -1118,7 +1142,7 @@ extern "C" int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, i
         }
     }
     Gemm16Args g = {c, p, q, (uint32_t)((uint64_t)t * ldp * 2), (uint32_t)((uint64_t)t * ldq * 2), (uint32_t)ldp, (uint32_t)ldq,
-                    (uint32_t)ldc, (uint32_t)m, (uint32_t)n, tm, tn, (int)stages, (int)sps};
+                    (uint32_t)ldc, (uint32_t)m, (uint32_t)n, tm, tn, (int)stages, (int)sp, tri};
     hipLaunchKernelGGL(k_gemm16t, dim3((unsigned)(tiles * sp)), dim3(256), lds_bytes, (hipStream_t)stream, g);
     return launch_status("gemm_bf16_tn_acc");
 }

@@ -412,20 +412,30 @@ def _split3(x: torch.Tensor, contract_cols: bool, order: int, negate: bool = Fal
     return dst
 
 
+def _bf16x3_route(m: int, k: int, n: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, tri: int = 0) -> bool:
+    """Whether a product goes to the bf16 split kernels: large enough (a triangular one has half the flops), aligned,
+    and addressable with the 32-bit offsets of the kernel's buffer reads."""
+    flops = 2.0 * m * k * n * (0.5 if tri else 1.0)
+    return (A.is_cuda and flops >= BF16X3_MIN_FLOPS and m % 8 == 0 and n % 8 == 0 and 12 * k * max(m, n) < 2 ** 32
+            and A.dtype == B.dtype == out.dtype == torch.float32 and A.stride(1) == 1 and B.stride(1) == 1
+            and out.stride(1) == 1)
+
+
 def _mm(out: torch.Tensor, A: torch.Tensor, B: torch.Tensor, b_t: bool = False, acc: Optional[torch.Tensor] = None,
-        negate: bool = False) -> torch.Tensor:
+        negate: bool = False, tri: int = 0) -> torch.Tensor:
     """out = (acc | 0) +- A @ (B^T if b_t else B), fp32 in and out (`acc` may be `out`).  Large products run on the
     bf16 MFMA: both operands as their exact three-way bf16 split, six-fold along the contraction (k_split3_*), then
     ONE hand-written GEMM over the 6x longer contraction with fp32 accumulation (k_gemm16t, the Hessian kernel's tile
     engine; csrc/wc_hessian.hip) -- the six leading products of the fp32 product, as accurate as the fp32 GEMM
     (measured 5e-7..9e-6 against 4e-7..5e-6 of max|C|), at 1.17-1.32 PFLOP/s = 170-205 TFLOP/s of fp32 work where the
     library's fp32 GEMM does 119-153: far trailing update 8192 x 1024 x 27648 3.51 -> 2.44 ms incl. the splits, X T^T
-    at n = 14336 38.6 -> 29.6 ms, n = 3584 0.77 -> 0.65 ms.  Smaller or unaligned products keep the fp32 GEMM."""
+    at n = 14336 38.6 -> 29.6 ms, n = 3584 0.77 -> 0.65 ms.  Smaller or unaligned products keep the fp32 GEMM.
+    `tri` (bf16 route only; the fp32 GEMM computes everything): the triangular structure the kernel may exploit, see
+    nncf_amd_gemm_bf16_tn_acc -- 1: B^T with B lower triangular, 2: B lower triangular, 3: A lower triangular, 4: only
+    the lower triangle of `out` is wanted."""
     m, k = A.shape
     n = B.shape[0] if b_t else B.shape[1]
-    if (A.is_cuda and 2.0 * m * k * n >= BF16X3_MIN_FLOPS and m % 8 == 0 and n % 8 == 0 and 12 * k * max(m, n) < 2 ** 32
-            and A.dtype == B.dtype == out.dtype == torch.float32 and A.stride(1) == 1 and B.stride(1) == 1
-            and out.stride(1) == 1):
+    if _bf16x3_route(m, k, n, A, B, out, tri):
         with torch.cuda.device(A.device):
             p6 = _split3(A, True, 0, negate)
             q6 = _split3(B, b_t, 1)
@@ -434,12 +444,13 @@ def _mm(out: torch.Tensor, A: torch.Tensor, B: torch.Tensor, b_t: bool = False, 
             elif acc is not out and (acc.data_ptr() != out.data_ptr() or acc.stride() != out.stride()):
                 out.copy_(acc)
             _lib.check(_lib.lib().nncf_amd_gemm_bf16_tn_acc(_lib.ptr(out), out.stride(0), _lib.ptr(p6), m, _lib.ptr(q6), n,
-                                                            m, n, 6 * k, _lib.stream_of(out)))
+                                                            m, n, 6 * k, tri, _lib.stream_of(out)))
         return out
     Bm = B.T if b_t else B
     if acc is None:
-        torch.matmul(A, Bm, out=out)
-        return out.neg_() if negate else out
+        if negate:
+            return torch.addmm(out, A, Bm, beta=0.0, alpha=-1.0, out=out)  # (beta = 0: `out` is not read)
+        return torch.matmul(A, Bm, out=out)
     return torch.addmm(acc, A, Bm, beta=1.0, alpha=-1.0 if negate else 1.0, out=out)
 
 
@@ -449,6 +460,8 @@ def _mm_dense_lowerT(X: torch.Tensor, T: torch.Tensor, out: Optional[torch.Tenso
     n = T.shape[0]
     if out is None:
         out = torch.empty((X.shape[0], n), dtype=X.dtype, device=X.device)
+    if _bf16x3_route(X.shape[0], n, n, X, T, out, tri=1):
+        return _mm(out, X, T, b_t=True, tri=1)  # one launch, the zero tiles of T skipped in the kernel
     if n < TRI_SPLIT_MIN:
         return _mm(out, X, T, b_t=True)
     h = ((n // 2 + 127) // 128) * 128
@@ -463,6 +476,8 @@ def _mm_dense_lower(X: torch.Tensor, T: torch.Tensor, out: Optional[torch.Tensor
     n = T.shape[0]
     if out is None:
         out = torch.empty((X.shape[0], n), dtype=X.dtype, device=X.device)
+    if _bf16x3_route(X.shape[0], n, n, X, T, out, tri=2):
+        return _mm(out, X, T, tri=2)
     if n < TRI_SPLIT_MIN:
         return _mm(out, X, T)
     h = ((n // 2 + 127) // 128) * 128
@@ -472,36 +487,39 @@ def _mm_dense_lower(X: torch.Tensor, T: torch.Tensor, out: Optional[torch.Tensor
     return out
 
 
-def _mm_lower_dense(T: torch.Tensor, X: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """T @ X for lower-triangular T: [[T11 X1], [T21 X1 + T22 X2]]."""
+def _mm_lower_dense(T: torch.Tensor, X: torch.Tensor, out: torch.Tensor, negate: bool = False) -> torch.Tensor:
+    """+-T @ X for lower-triangular T: [[T11 X1], [T21 X1 + T22 X2]]."""
     n = T.shape[0]
+    if _bf16x3_route(n, n, X.shape[1], T, X, out, tri=3):
+        return _mm(out, T, X, negate=negate, tri=3)
     if n < TRI_SPLIT_MIN:
-        return _mm(out, T, X)
+        return _mm(out, T, X, negate=negate)
     h = ((n // 2 + 127) // 128) * 128
-    _mm_lower_dense(T[:h, :h], X[:h], out[:h])
-    _mm_lower_dense(T[h:, h:], X[h:], out[h:])
-    _mm(out[h:], T[h:, :h], X[:h], acc=out[h:])
+    _mm_lower_dense(T[:h, :h], X[:h], out[:h], negate)
+    _mm_lower_dense(T[h:, h:], X[h:], out[h:], negate)
+    _mm(out[h:], T[h:, :h], X[:h], acc=out[h:], negate=negate)
     return out
 
 
 def _syrk_lower_sub(C: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
-    """Lower triangle of C - A A^T into a new matrix (the strictly upper part is left unspecified: only the lower
-    triangle of a Schur complement is ever read)."""
-    n = C.shape[0]
-    S = torch.empty_like(C)
+    """Lower triangle of C - A A^T, IN PLACE in C (the strictly upper part is left unspecified: only the lower triangle
+    of a Schur complement is ever read, and C is the recursion's own copy of the matrix)."""
 
-    def rec(S, C, A):
+    def rec(C, A):
         m = C.shape[0]
+        if _bf16x3_route(m, A.shape[1], m, A, A, C, tri=4):
+            _mm(C, A, A, b_t=True, acc=C, negate=True, tri=4)
+            return
         if m < TRI_SPLIT_MIN:
-            _mm(S, A, A, b_t=True, acc=C, negate=True)
+            _mm(C, A, A, b_t=True, acc=C, negate=True)
             return
         h = ((m // 2 + 127) // 128) * 128
-        rec(S[:h, :h], C[:h, :h], A[:h])
-        rec(S[h:, h:], C[h:, h:], A[h:])
-        _mm(S[h:, :h], A[h:], A[:h], b_t=True, acc=C[h:, :h], negate=True)
+        rec(C[:h, :h], A[:h])
+        rec(C[h:, h:], A[h:])
+        _mm(C[h:, :h], A[h:], A[:h], b_t=True, acc=C[h:, :h], negate=True)
 
-    rec(S, C, A)
-    return S
+    rec(C, A)
+    return C
 
 
 def _cholinv_base(A: torch.Tensor, Linv: torch.Tensor, info: torch.Tensor) -> None:
@@ -516,7 +534,8 @@ def _cholinv_base(A: torch.Tensor, Linv: torch.Tensor, info: torch.Tensor) -> No
 
 def _cholinv_lower(A: torch.Tensor, Linv: torch.Tensor, info: torch.Tensor) -> None:
     """Writes L^-1 (lower triangle; the caller zero-fills the rest) of the SPD matrix A = L L^T into `Linv`; only
-    the lower triangle of A is read.  With A = [[A11, .], [A21, A22]]:
+    the lower triangle of A is read, and A is OVERWRITTEN (its trailing blocks become the Schur complements).  With
+    A = [[A11, .], [A21, A22]]:
         I11 = rec(A11);  L21 = A21 I11^T;  S = A22 - L21 L21^T;  I22 = rec(S);  I21 = -I22 (L21 I11)
     i.e. everything above the base size is a plain fp32 GEMM (hipBLASLt runs them at ~150 TFLOP/s on MI355X, the
     library potrf / trsm chain at 35-60), and the inverse factor comes out of ONE sweep instead of a factorization
@@ -534,11 +553,9 @@ def _cholinv_lower(A: torch.Tensor, Linv: torch.Tensor, info: torch.Tensor) -> N
     L21 = _mm_dense_lowerT(A[h:, :h], I11)
     S = _syrk_lower_sub(A[h:, h:], L21)
     _cholinv_lower(S, Linv[h:, h:], info)
-    del S
     tmp = _mm_dense_lower(L21, I11)
     del L21
-    _mm_lower_dense(Linv[h:, h:], tmp, Linv[h:, :h])
-    Linv[h:, :h].neg_()
+    _mm_lower_dense(Linv[h:, h:], tmp, Linv[h:, :h], negate=True)
 
 
 _NOT_SPD = "linalg.cholesky: The factorization could not be completed because the input is not positive-definite"

@@ -49,8 +49,12 @@ def test_triangular_products(small_bases):
     torch.testing.assert_close(G._mm_lower_dense(T, Y, out), T @ Y)
     C = torch.randn(n, n, dtype=torch.float64)
     A = torch.randn(n, 96, dtype=torch.float64)
-    S = G._syrk_lower_sub(C, A)
-    torch.testing.assert_close(torch.tril(S), torch.tril(C - A @ A.T))
+    want = torch.tril(C - A @ A.T)
+    S = G._syrk_lower_sub(C, A)  # in place: C is the recursion's own copy
+    assert S.data_ptr() == C.data_ptr()
+    torch.testing.assert_close(torch.tril(S), want)
+    out2 = torch.empty(n, 200, dtype=torch.float64)
+    torch.testing.assert_close(G._mm_lower_dense(T, Y, out2, negate=True), -(T @ Y))
 
 
 def test_prepare_hinv_dead_columns_and_damping():

@@ -740,7 +740,7 @@ def test_gemm_bf16_tn_acc_matches_float64(m, k, n):
     guard = Cfull[:, :16].clone()
     P = _split3_call(A, True, 0, negate=True)
     Q = _split3_call(B, False, 1)
-    _lib.check(_lib.lib().nncf_amd_gemm_bf16_tn_acc(_lib.ptr(C), C.stride(0), _lib.ptr(P), m, _lib.ptr(Q), n, m, n, 6 * k,
+    _lib.check(_lib.lib().nncf_amd_gemm_bf16_tn_acc(_lib.ptr(C), C.stride(0), _lib.ptr(P), m, _lib.ptr(Q), n, m, n, 6 * k, 0,
                                                     _lib.stream_of(C)))
     err = float((C.double() - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
@@ -749,7 +749,7 @@ def test_gemm_bf16_tn_acc_matches_float64(m, k, n):
     C2 = torch.zeros(m, n, device="cuda")
     Q2 = _split3_call(B.T.contiguous(), True, 1)
     assert torch.equal(Q2, Q)
-    _lib.check(_lib.lib().nncf_amd_gemm_bf16_tn_acc(_lib.ptr(C2), n, _lib.ptr(P), m, _lib.ptr(Q2), n, m, n, 6 * k,
+    _lib.check(_lib.lib().nncf_amd_gemm_bf16_tn_acc(_lib.ptr(C2), n, _lib.ptr(P), m, _lib.ptr(Q2), n, m, n, 6 * k, 0,
                                                     _lib.stream_of(C2)))
     ref2 = -(A.double() @ B.double())
     assert float((C2.double() - ref2).abs().max() / ref2.abs().max()) < 2e-6
@@ -760,9 +760,9 @@ def test_gemm_bf16_tn_acc_rejects_what_it_cannot_address():
     L = _lib.lib()
     c = torch.zeros(8, 8, device="cuda")
     p = torch.zeros(6, 8, dtype=torch.bfloat16, device="cuda")
-    assert L.nncf_amd_gemm_bf16_tn_acc(_lib.ptr(c), 8, _lib.ptr(p), 4, _lib.ptr(p), 8, 8, 8, 6, None) == _lib.ERR_BAD_ARG  # ldp < m
-    assert L.nncf_amd_gemm_bf16_tn_acc(_lib.ptr(c), 8, _lib.ptr(p), 12, _lib.ptr(p), 8, 8, 8, 6, None) == _lib.ERR_UNSUPPORTED  # pitch % 8
-    assert L.nncf_amd_gemm_bf16_tn_acc(_lib.ptr(c), 8, _lib.ptr(p), 8, _lib.ptr(p), 8, 8, 8, 1 << 29, None) == _lib.ERR_UNSUPPORTED  # >= 4 GiB
+    assert L.nncf_amd_gemm_bf16_tn_acc(_lib.ptr(c), 8, _lib.ptr(p), 4, _lib.ptr(p), 8, 8, 8, 6, 0, None) == _lib.ERR_BAD_ARG  # ldp < m
+    assert L.nncf_amd_gemm_bf16_tn_acc(_lib.ptr(c), 8, _lib.ptr(p), 12, _lib.ptr(p), 8, 8, 8, 6, 0, None) == _lib.ERR_UNSUPPORTED  # pitch % 8
+    assert L.nncf_amd_gemm_bf16_tn_acc(_lib.ptr(c), 8, _lib.ptr(p), 8, _lib.ptr(p), 8, 8, 8, 1 << 29, 0, None) == _lib.ERR_UNSUPPORTED  # >= 4 GiB
 
 
 def test_mm_takes_the_same_decision_for_both_routes():
@@ -788,3 +788,33 @@ def test_mm_takes_the_same_decision_for_both_routes():
                 out3 = torch.empty(m, n, device="cuda")
                 gptq._mm(out3, A, B, b_t=b_t, acc=C, negate=negate)
                 assert float((out3.double() - ref).abs().max() / ref.abs().max()) < 4e-6
+
+
+@pytest.mark.parametrize("n", [3328, 3336])
+def test_triangular_products_in_one_launch(n):
+    """The four products of a level of the Hinv recursion through k_gemm16t with the zero / unwanted tiles skipped in
+    the kernel (tri = 1..4) against float64: X T^T, X T, T X for a lower triangular T, and the lower triangle of
+    C - A A^T.  n = 3336: a ragged last tile."""
+    from nncf_amd import gptq
+    g = torch.Generator(device="cuda").manual_seed(n)
+    X = torch.randn(n, n, device="cuda", generator=g)
+    T = torch.tril(torch.randn(n, n, device="cuda", generator=g))
+    assert gptq._bf16x3_route(n, n, n, X, T, X, tri=1)
+
+    def close(got, ref, mask=None):
+        d = (got.double() - ref).abs()
+        if mask is not None:
+            d = d * mask
+        return float(d.max() / ref.abs().max())
+
+    assert close(gptq._mm_dense_lowerT(X, T), X.double() @ T.double().T) < 4e-6
+    assert close(gptq._mm_dense_lower(X, T), X.double() @ T.double()) < 4e-6
+    out = torch.empty(n, n, device="cuda")
+    assert close(gptq._mm_lower_dense(T, X, out), T.double() @ X.double()) < 4e-6
+    C = torch.randn(n, n, device="cuda", generator=g)
+    A = torch.randn(n, 2048, device="cuda", generator=g)
+    lower = torch.tril(torch.ones(n, n, device="cuda", dtype=torch.float64))
+    ref = C.double() - A.double() @ A.double().T
+    got = gptq._syrk_lower_sub(C, A)  # in place
+    assert got.data_ptr() == C.data_ptr()
+    assert close(got, ref, lower) < 4e-6
