@@ -578,32 +578,76 @@ struct Gemm16Args {
     uint32_t M, N;
     int tm, tn, stages, splits;
     int tri;  // which stages / tiles can contribute (a triangular operand or result), see nncf_amd_gemm_bf16_tn_acc
+    int xcd_lists;  // tile order of a triangular product: per-XCD lists (large tile counts) or alternating bands
 };
 
 __global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
     extern __shared__ __attribute__((aligned(1024))) char smem16[];  // [GST][A, B][GK * GROW]
-    // block -> (split, tile): XCD x takes the x-th contiguous eighth of the list; tiles go band by band (4 tile lines),
-    // line by line inside a band, so the blocks that share an L2 share panels.  A triangular product's work per tile
-    // changes along one axis: the bands run ACROSS that axis (every band then has the same work), and both the bands
-    // and the positions inside a band are taken alternately from the two ends (0, last, 1, last - 1, ...), so that any
-    // contiguous run of the list -- an XCD's eighth, the tail of the launch -- mixes light and heavy tiles.
-    const uint32_t tiles = (uint32_t)(g.tm * g.tn), total = gridDim.x;
+    // block -> (tile, split).  Blocks go round-robin over the 8 XCDs (block b runs on XCD b % 8), each with an L2 of its
+    // own, so the blocks of one XCD should share panels and every XCD should get the same work.
+    //   dense (tri 0): XCD x takes the x-th contiguous eighth of the tile list, tiles band by band (4 tile rows),
+    //     column by column inside a band;
+    //   triangular operand (tri 1..3): the work of a tile changes along ONE axis by a factor of up to the tile count
+    //     (48 .. 48 * tn stages).  XCD x owns the lines across that axis with index = x (mod 8) -- every XCD the same
+    //     work -- and walks its tiles heaviest first (longest-processing-time order: the tail of the launch is made of
+    //     the lightest tiles); ~7 lines x ~5 positions are in flight per XCD: 12 panels;
+    //   lower triangle wanted (tri 4): tiles of equal work, tile rows dealt to the XCDs back and forth (x, 15 - x,
+    //     16 + x, 31 - x, ...) so that the row lengths even out.
+    // The `splits` parts of a tile are neighbours in an XCD's list.
+    //   Few tiles (an XCD would own 1-3 lines: uneven shares): the contiguous-eighth list of the dense case with the
+    //     bands ACROSS the axis along which the work changes (every band the same work), bands and positions inside a
+    //     band taken alternately from both ends (0, last, 1, last - 1, ...): every run of the list mixes light and heavy.
     const uint32_t lin = blockIdx.x, xcd = lin & 7, nth = lin >> 3;
-    const uint32_t logical = xcd * (total >> 3) + (xcd < (total & 7) ? xcd : (total & 7)) + nth;
-    const int split = (int)(logical / tiles);
-    const uint32_t qid = logical % tiles;
-    const bool across_cols = g.tri == 3 || g.tri == 4;  // work changes with the row of C: bands of tile columns
-    const uint32_t outer_n = (uint32_t)(across_cols ? g.tn : g.tm), inner_n = (uint32_t)(across_cols ? g.tm : g.tn);
-    const uint32_t nb = (outer_n + 3) / 4, rs = outer_n - 4 * (nb - 1), full = 4 * inner_n, shrt = rs * inner_n;
-    uint32_t seq, in_band;  // the short band (the last one) sits at position 1 of the alternating order
-    if (nb == 1 || qid < full) seq = 0, in_band = qid;
-    else if (qid < full + shrt) seq = 1, in_band = qid - full;
-    else seq = 2 + (qid - full - shrt) / full, in_band = (qid - full - shrt) % full;
-    const uint32_t band = (seq & 1) ? nb - 1 - (seq >> 1) : (seq >> 1);
-    const uint32_t lines = band == nb - 1 ? rs : 4;
-    const uint32_t line = band * 4 + in_band % lines, qc = in_band / lines;
-    const uint32_t inner = (qc & 1) ? inner_n - 1 - (qc >> 1) : (qc >> 1);
-    const int ti = (int)(across_cols ? inner : line), tj = (int)(across_cols ? line : inner);
+    int ti, tj, split;
+    if (g.tri == 0 || !g.xcd_lists) {
+        const uint32_t tiles = (uint32_t)(g.tm * g.tn), total = gridDim.x;
+        const uint32_t logical = xcd * (total >> 3) + (xcd < (total & 7) ? xcd : (total & 7)) + nth;
+        split = (int)(logical / tiles);
+        const uint32_t qid = logical % tiles;
+        const bool across_cols = g.tri == 3 || g.tri == 4;  // work changes with the row of C: bands of tile columns
+        const uint32_t outer_n = (uint32_t)(across_cols ? g.tn : g.tm), inner_n = (uint32_t)(across_cols ? g.tm : g.tn);
+        const uint32_t nb = (outer_n + 3) / 4, rs = outer_n - 4 * (nb - 1), full = 4 * inner_n, shrt = rs * inner_n;
+        const bool alt = g.tri != 0;
+        uint32_t seq, in_band;  // (alternating order: the short last band sits at position 1)
+        if (!alt) seq = qid / full, in_band = qid % full;
+        else if (nb == 1 || qid < full) seq = 0, in_band = qid;
+        else if (qid < full + shrt) seq = 1, in_band = qid - full;
+        else seq = 2 + (qid - full - shrt) / full, in_band = (qid - full - shrt) % full;
+        const uint32_t band = !alt ? seq : ((seq & 1) ? nb - 1 - (seq >> 1) : (seq >> 1));
+        const uint32_t lines = band == nb - 1 ? rs : 4;
+        const uint32_t line = band * 4 + in_band % lines, qc = in_band / lines;
+        const uint32_t inner = !alt ? qc : ((qc & 1) ? inner_n - 1 - (qc >> 1) : (qc >> 1));
+        ti = (int)(across_cols ? inner : line), tj = (int)(across_cols ? line : inner);
+    } else {
+        split = (int)(nth % (uint32_t)g.splits);
+        const uint32_t idx = nth / (uint32_t)g.splits;
+        if (g.tri == 4) {
+            uint32_t left = idx;
+            int row = -1;
+            for (int b = 0;; ++b) {
+                const int r = 16 * (b >> 1) + ((b & 1) ? 15 - (int)xcd : (int)xcd);
+                if (r >= g.tm) break;
+                const uint32_t cnt = (uint32_t)((r < g.tn ? r : g.tn - 1) + 1);  // tiles tj <= ti of this row
+                if (left < cnt) {
+                    row = r;
+                    break;
+                }
+                left -= cnt;
+            }
+            if (row < 0) return;
+            ti = row;
+            tj = (int)left;
+        } else {
+            const int span = g.tri == 3 ? g.tn : g.tm;      // the lines an XCD owns run along this many tiles ...
+            const int along = g.tri == 3 ? g.tm : g.tn;     // ... and each is this long
+            const int nlines = (int)xcd < span ? (span - (int)xcd + 7) / 8 : 0;
+            if (idx >= (uint32_t)(nlines * along)) return;
+            const int line = (int)xcd + 8 * (int)(idx % (uint32_t)nlines), pos = (int)(idx / (uint32_t)nlines);
+            if (g.tri == 1) ti = line, tj = along - 1 - pos;       // heaviest: the last column
+            else if (g.tri == 2) ti = line, tj = pos;              // heaviest: the first column
+            else ti = along - 1 - pos, tj = line;                  // heaviest: the last row
+        }
+    }
     const uint32_t i0 = (uint32_t)ti * GB, j0 = (uint32_t)tj * GB;
     // the stages of this tile that can contribute: contraction index t = row / 6 of P and Q (slot-minor rows), so a
     // 256-wide tile of a triangular operand bounds the rows at a multiple of 6 * 256 = 48 stages
@@ -802,13 +846,21 @@ __global__ __launch_bounds__(256) void k_split3_rows(const float* __restrict__ s
         const float x = i < nc ? src[r * src_pitch + c + i] * sign : 0.0f;
         split3_of(x, piece[0][i], piece[1][i], piece[2][i]);
     }
+    const bool vec = nc == 4 && (dst_pitch & 3) == 0 && (((uintptr_t)dst) & 7u) == 0;  // (c is a multiple of 4)
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const int p = split3_slot_piece(order, s);
         uint16_t* out = dst + (r * 6 + s) * dst_pitch + c;
+        uint32_t v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < nc) out[i] = (uint16_t)(p == 0 ? piece[0][i] : (p == 1 ? piece[1][i] : piece[2][i]));
+        for (int i = 0; i < 4; ++i) v[i] = p == 0 ? piece[0][i] : (p == 1 ? piece[1][i] : piece[2][i]);
+        if (vec) {
+            *(uint2*)out = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nc) out[i] = (uint16_t)v[i];
+        }
     }
 }
 
@@ -1142,7 +1194,34 @@ extern "C" int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, i
         }
     }
     Gemm16Args g = {c, p, q, (uint32_t)((uint64_t)t * ldp * 2), (uint32_t)((uint64_t)t * ldq * 2), (uint32_t)ldp, (uint32_t)ldq,
-                    (uint32_t)ldc, (uint32_t)m, (uint32_t)n, tm, tn, (int)stages, (int)sp, tri};
-    hipLaunchKernelGGL(k_gemm16t, dim3((unsigned)(tiles * sp)), dim3(256), lds_bytes, (hipStream_t)stream, g);
+                    (uint32_t)ldc, (uint32_t)m, (uint32_t)n, tm, tn, (int)stages, (int)sp, tri, 0};
+    // tile order of a triangular product: per-XCD lists where every XCD gets (nearly) the same number of lines
+    // (measured: tri 1-3 from 28 tiles across on, tri 4 at 56; 14 tiles across: the alternating bands are faster)
+    g.xcd_lists = tri == 0 ? 0 : (tri == 4 ? tm >= 48 : (tri == 3 ? tn : tm) >= 24);
+    // blocks: 8 XCD lists of equal length (the kernel's mapping; lists that run out return at once)
+    int64_t per_xcd = 0;
+    if (!g.xcd_lists) {
+        per_xcd = (tiles * sp + 7) / 8;
+    } else if (tri == 4) {
+        for (int x = 0; x < 8; ++x) {
+            int64_t cnt = 0;
+            for (int b = 0;; ++b) {
+                const int r = 16 * (b >> 1) + ((b & 1) ? 15 - x : x);
+                if (r >= tm) break;
+                cnt += (r < tn ? r : tn - 1) + 1;
+            }
+            if (cnt > per_xcd) per_xcd = cnt;
+        }
+        per_xcd *= sp;
+    } else {
+        const int span = tri == 3 ? tn : tm, along = tri == 3 ? tm : tn;
+        per_xcd = (int64_t)((span + 7) / 8) * along * sp;
+    }
+    const int64_t blocks = !g.xcd_lists ? tiles * sp : per_xcd * 8;
+    if (blocks > 0x7fffffffLL) {
+        set_error("gemm_bf16_tn_acc: too many tiles");
+        return NNCF_AMD_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_gemm16t, dim3((unsigned)blocks), dim3(256), lds_bytes, (hipStream_t)stream, g);
     return launch_status("gemm_bf16_tn_acc");
 }
