@@ -106,9 +106,14 @@ def test_c3_awq_search_full_size():
 def test_c4_gptq_full_size():
     """K = 8192 (Llama-3-70B hidden), INT4_SYM g64, 16k calibration tokens in bf16: U^T U H = I, every quantized value
     sits on its group's scale grid inside the INT4 range, the layer output error tr((W-Q) H (W-Q)^T) is below
-    round-to-nearest's, and the column sweep equals the oracle's on a 32-row slice given the same U."""
+    round-to-nearest's, and the column sweep equals the oracle's on a 32-row slice given the same U.  4096 rows: the far
+    trailing updates (2 * 4096 * 1024 * 7168 flops and less) and the top of the Hinv recursion run on the bf16 split
+    kernels (gptq._mm), the rest on the fp32 GEMM."""
     from nncf_amd import gptq, weight_lowering as wl
-    K, N, gs = 8192, 512, 64
+    K, N, gs = 8192, 4096, 64
+    far = torch.empty(N, K - 1024, device="cuda")
+    assert gptq._bf16x3_route(N, 1024, K - 1024, far[:, :1024], far[:1024], far)
+    del far
     g = torch.Generator(device="cuda").manual_seed(8)
     chan = torch.ones(K, device="cuda")
     chan[::97] = 6.0
