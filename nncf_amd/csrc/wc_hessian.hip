@@ -13,6 +13,7 @@
 // The token axis is split over gridDim.y when there are too few tile pairs to fill 256 CUs; partial products
 // are combined with fp32 atomic adds (H is pre-scaled by beta in a separate pass), so the low-order bits of H
 // can differ from run to run by summation order -- well inside the 1e-5 relative contract.
+#include <stdlib.h>
 #include <type_traits>
 #include "wc_common.h"
 
@@ -579,9 +580,15 @@ struct Gemm16Args {
     int tm, tn, stages, splits;
     int tri;  // which stages / tiles can contribute (a triangular operand or result), see nncf_amd_gemm_bf16_tn_acc
     int xcd_lists;  // tile order of a triangular product: per-XCD lists (large tile counts) or alternating bands
+    uint32_t wanted;  // tri 4 with lists: number of tiles tj <= ti
+    float alpha;      // list form (Hessian): factor of the accumulated product
 };
 
-__global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
+// LIST: P = Q = a LIST of separately allocated 16-bit items [tokens_i, K] (the calibration activations: H += alpha X^T X
+// without a concatenation copy), tri = 4 with the tile transposed (the UPPER triangle is accumulated, k_mirror_upper
+// fills in the rest); stages never straddle items, an item's rows past its end read as zero through its own descriptor.
+template <int DT, bool LIST>
+__device__ __forceinline__ void gemm16t_body(const Gemm16Args& g, const SyrkItems* items) {
     extern __shared__ __attribute__((aligned(1024))) char smem16[];  // [GST][A, B][GK * GROW]
     // block -> (tile, split).  Blocks go round-robin over the 8 XCDs (block b runs on XCD b % 8), each with an L2 of its
     // own, so the blocks of one XCD should share panels and every XCD should get the same work.
@@ -622,21 +629,35 @@ __global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
         split = (int)(nth % (uint32_t)g.splits);
         const uint32_t idx = nth / (uint32_t)g.splits;
         if (g.tri == 4) {
-            uint32_t left = idx;
-            int row = -1;
-            for (int b = 0;; ++b) {
-                const int r = 16 * (b >> 1) + ((b & 1) ? 15 - (int)xcd : (int)xcd);
-                if (r >= g.tm) break;
-                const uint32_t cnt = (uint32_t)((r < g.tn ? r : g.tn - 1) + 1);  // tiles tj <= ti of this row
-                if (left < cnt) {
-                    row = r;
-                    break;
-                }
-                left -= cnt;
+            // tiles tj <= ti only, all of equal work: XCD x takes the x-th contiguous eighth of the list, the list goes
+            // band by band (4 tile rows), column by column inside a band: 4 x 8 tiles in flight per XCD = 12 panels
+            const uint32_t total = g.wanted;
+            const uint32_t logical = xcd * (total >> 3) + (xcd < (total & 7) ? xcd : (total & 7)) + idx;
+            if (idx >= (total >> 3) + (xcd < (total & 7) ? 1u : 0u)) return;
+            uint32_t q = logical;
+            int r0 = 0, rows = 0;
+            for (;; r0 += 4) {
+                rows = g.tm - r0 < 4 ? g.tm - r0 : 4;
+                uint32_t in_band = 0;
+                for (int r = r0; r < r0 + rows; ++r) in_band += (uint32_t)((r < g.tn ? r : g.tn - 1) + 1);
+                if (q < in_band) break;
+                q -= in_band;
             }
-            if (row < 0) return;
-            ti = row;
-            tj = (int)left;
+            const uint32_t full_cols = (uint32_t)(r0 < g.tn ? r0 : g.tn);  // columns every row of the band has
+            if (q < full_cols * (uint32_t)rows) {
+                tj = (int)(q / (uint32_t)rows);
+                ti = r0 + (int)(q % (uint32_t)rows);
+            } else {
+                q -= full_cols * (uint32_t)rows;
+                int c = r0;
+                for (;; ++c) {  // the band's own diagonal block: column c holds rows max(c, r0) .. r0 + rows - 1
+                    const uint32_t cnt = (uint32_t)(r0 + rows - c);
+                    if (q < cnt) break;
+                    q -= cnt;
+                }
+                tj = c;
+                ti = c + (int)q;
+            }
         } else {
             const int span = g.tri == 3 ? g.tn : g.tm;      // the lines an XCD owns run along this many tiles ...
             const int along = g.tri == 3 ? g.tm : g.tn;     // ... and each is this long
@@ -648,6 +669,11 @@ __global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
             else ti = along - 1 - pos, tj = line;                  // heaviest: the last row
         }
     }
+    if constexpr (LIST) {  // (tj <= ti from the lower-triangle list) -> the upper tile
+        const int sw = ti;
+        ti = tj;
+        tj = sw;
+    }
     const uint32_t i0 = (uint32_t)ti * GB, j0 = (uint32_t)tj * GB;
     // the stages of this tile that can contribute: contraction index t = row / 6 of P and Q (slot-minor rows), so a
     // 256-wide tile of a triangular operand bounds the rows at a multiple of 6 * 256 = 48 stages
@@ -656,7 +682,7 @@ __global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
     if (g.tri == 1) hi = (tj + 1) * kStagesPerTile;        // Q^T lower triangular: t <= column of C
     else if (g.tri == 2) lo = tj * kStagesPerTile;         // Q lower triangular:   t >= column of C
     else if (g.tri == 3) hi = (ti + 1) * kStagesPerTile;   // P^T lower triangular: t <= row of C
-    else if (g.tri == 4 && tj > ti) return;                // only the lower triangle of C is wanted
+    else if (g.tri == 4 && !LIST && tj > ti) return;       // only the lower triangle of C is wanted
     if (hi > g.stages) hi = g.stages;
     if (lo >= hi) return;
     // every tile's own range in `splits` equal parts
@@ -674,7 +700,19 @@ __global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     i32x4 rsrc_p, rsrc_q;
-    {
+    int cur_item = 0;
+    auto set_item = [&](int it) {  // LIST: both operands read the item of the stage being requested
+        const uintptr_t base = (uintptr_t)items->x[it];
+        rsrc_p[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        rsrc_p[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((base >> 32) & 0xffffu));
+        rsrc_p[2] = __builtin_amdgcn_readfirstlane((int)items->bytes[it]);
+        rsrc_p[3] = 0x00020000;
+        rsrc_q = rsrc_p;
+    };
+    if constexpr (LIST) {
+        while ((uint32_t)s_begin >= items->stage_start[cur_item + 1]) ++cur_item;
+        set_item(cur_item);
+    } else {
         const uintptr_t bp = (uintptr_t)g.p, bq = (uintptr_t)g.q;
         rsrc_p[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)bp);
         rsrc_p[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((bp >> 32) & 0xffffu));
@@ -697,9 +735,20 @@ __global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
     const int nst = s_end - s_begin;
     const uint32_t lds_base = (uint32_t)(uintptr_t)smem16;
     uint32_t dma_dst = 0, so_p = 0, so_q = 0;
+    uint32_t cur_start = 0, next_start = 0xffffffffu;  // SGPRs: no loads per stage
+    if constexpr (LIST) cur_start = items->stage_start[cur_item], next_start = items->stage_start[cur_item + 1];
     auto issue_prepare = [&](int st) {
         dma_dst = lds_base + (uint32_t)((st % GST) * (2 * GK * GROW) + 8 * wave * GROW);
-        const uint32_t gst = (uint32_t)(s_begin + st);
+        uint32_t gst = (uint32_t)(s_begin + st);
+        if constexpr (LIST) {
+            if (gst >= next_start) {  // wave-uniform
+                do ++cur_item; while (gst >= items->stage_start[cur_item + 1]);
+                cur_start = items->stage_start[cur_item];
+                next_start = items->stage_start[cur_item + 1];
+                set_item(cur_item);
+            }
+            gst -= cur_start;
+        }
         so_p = gst * GK * g.ldp * 2u + i0 * 2u;
         so_q = gst * GK * g.ldq * 2u + j0 * 2u;
     };
@@ -729,7 +778,10 @@ __global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
         return __builtin_bit_cast(op_t, pr);
     };
     auto mfma = [&](f32x16& c, const op_t& a, const op_t& b) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
+        if constexpr (DT == NNCF_AMD_BF16)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
+        else
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
     };
     auto wait_dma = [&](int outstanding) {
         switch (outstanding) {
@@ -809,9 +861,20 @@ __global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t gi = bi + m * 32 + (r & 3) + 8 * (r >> 2);
-                if (gi < g.M && gj < g.N) atomicAdd(g.c + ((uint64_t)gi * g.ldc + gj), acc[m][n][r]);
+                if constexpr (LIST) {
+                    if (gi <= gj && gj < g.N) atomicAdd(g.c + ((uint64_t)gi * g.ldc + gj), g.alpha * acc[m][n][r]);
+                } else {
+                    if (gi < g.M && gj < g.N) atomicAdd(g.c + ((uint64_t)gi * g.ldc + gj), acc[m][n][r]);
+                }
             }
         }
+}
+
+__global__ __launch_bounds__(256) void k_gemm16t(const Gemm16Args g) { gemm16t_body<NNCF_AMD_BF16, false>(g, nullptr); }
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_gemm16t_list(const Gemm16Args g, const SyrkItems items) {
+    gemm16t_body<DT, true>(g, &items);
 }
 
 // The six-fold three-way bf16 split of an fp32 matrix view, rows of the result = contraction index (what k_gemm16t
@@ -946,6 +1009,29 @@ static int launch_syrk16b_list(float* h, const wc::SyrkItems& items, int x_dtype
     const int64_t sps = (stages + sp - 1) / sp;
     sp = (stages + sps - 1) / sps;
     constexpr size_t lds_bytes = (size_t)GST * 2 * GK * GROW;  // 131072
+    // Many tile pairs: the two-operand kernel in its list form (k_gemm16t_list: no diagonal special case, 340 registers
+    // against 512 + spills) holds 1.30 PFLOP/s on a 73728 x 28672 bf16 chunk (46.7 ms; the whole accumulate call with
+    // its mirror pass 52.4 against 53.2 ms through k_syrk16b, a Llama-3-70B GPTQ layer 455 -> 452 ms); at K = 8192 (528
+    // pairs: rounds of blocks that do not fill) k_syrk16b stays ahead (14.1 against 15.0 ms).
+    static const int64_t list_min_tiles = [] { const char* e = getenv("NNCF_AMD_SYRK_LIST_TILES"); return e ? atoll(e) : 48ll; }();
+    if (nt >= list_min_tiles) {
+        static OncePerDevice attr_list;
+        if (attr_list.first_on_device() != 0) {
+            if (hipFuncSetAttribute((const void*)k_gemm16t_list<NNCF_AMD_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_gemm16t_list<NNCF_AMD_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+                attr_list.forget_current();
+                return launch_status("hessian gemm16t_list attribute");
+            }
+        }
+        Gemm16Args g = {h, nullptr, nullptr, 0u, 0u, (uint32_t)k, (uint32_t)k, (uint32_t)k, (uint32_t)k, (uint32_t)k, nt, nt,
+                        (int)stages, (int)sp, 4, 1, (uint32_t)prs, alpha};
+        const int64_t blocks = ((prs + 7) / 8) * sp * 8;
+        if (x_dtype == NNCF_AMD_BF16)
+            hipLaunchKernelGGL((k_gemm16t_list<NNCF_AMD_BF16>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, g, items);
+        else
+            hipLaunchKernelGGL((k_gemm16t_list<NNCF_AMD_F16>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, g, items);
+        return launch_status("hessian_gemm16t_list");
+    }
     static OncePerDevice attr_once;
     if (attr_once.first_on_device() != 0) {
         if (hipFuncSetAttribute((const void*)k_syrk16b<NNCF_AMD_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
@@ -1177,8 +1263,10 @@ extern "C" int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, i
     // >= 2 rounds of blocks over the 256 CUs where the contraction is long enough to split (>= 64 stages per block on
     // average; a triangular product has about half the tile x stage work of the full one)
     const int64_t work_tiles = tri == 0 ? tiles : (tiles + 1) / 2;
-    int64_t sp = work_tiles >= 512 ? 1 : (512 + work_tiles - 1) / work_tiles;
-    const int64_t maxsp = (stages + 63) / 64;
+    static const int64_t want_blocks = [] { const char* e = getenv("NNCF_AMD_GEMM_BLOCKS"); return e ? atoll(e) : 512ll; }();
+    static const int64_t min_stages = [] { const char* e = getenv("NNCF_AMD_GEMM_MINST"); return e ? atoll(e) : 64ll; }();
+    int64_t sp = work_tiles >= want_blocks ? 1 : (want_blocks + work_tiles - 1) / work_tiles;
+    const int64_t maxsp = (stages + min_stages - 1) / min_stages;
     if (sp > maxsp) sp = maxsp;
     if (sp < 1) sp = 1;
     if (tiles * sp > 0x7fffffffLL) {
@@ -1194,25 +1282,19 @@ extern "C" int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, i
         }
     }
     Gemm16Args g = {c, p, q, (uint32_t)((uint64_t)t * ldp * 2), (uint32_t)((uint64_t)t * ldq * 2), (uint32_t)ldp, (uint32_t)ldq,
-                    (uint32_t)ldc, (uint32_t)m, (uint32_t)n, tm, tn, (int)stages, (int)sp, tri, 0};
+                    (uint32_t)ldc, (uint32_t)m, (uint32_t)n, tm, tn, (int)stages, (int)sp, tri, 0, 0, 1.0f};
     // tile order of a triangular product: per-XCD lists where every XCD gets (nearly) the same number of lines
     // (measured: tri 1-3 from 28 tiles across on, tri 4 at 56; 14 tiles across: the alternating bands are faster)
-    g.xcd_lists = tri == 0 ? 0 : (tri == 4 ? tm >= 48 : (tri == 3 ? tn : tm) >= 24);
+    g.xcd_lists = tri == 0 ? 0 : (tri == 4 ? tm >= 8 : (tri == 3 ? tn : tm) >= 24);
     // blocks: 8 XCD lists of equal length (the kernel's mapping; lists that run out return at once)
     int64_t per_xcd = 0;
     if (!g.xcd_lists) {
         per_xcd = (tiles * sp + 7) / 8;
     } else if (tri == 4) {
-        for (int x = 0; x < 8; ++x) {
-            int64_t cnt = 0;
-            for (int b = 0;; ++b) {
-                const int r = 16 * (b >> 1) + ((b & 1) ? 15 - x : x);
-                if (r >= tm) break;
-                cnt += (r < tn ? r : tn - 1) + 1;
-            }
-            if (cnt > per_xcd) per_xcd = cnt;
-        }
-        per_xcd *= sp;
+        int64_t wanted = 0;
+        for (int r = 0; r < tm; ++r) wanted += (r < tn ? r : tn - 1) + 1;
+        g.wanted = (uint32_t)wanted;
+        per_xcd = ((wanted + 7) / 8) * sp;
     } else {
         const int span = tri == 3 ? tn : tm, along = tri == 3 ? tm : tn;
         per_xcd = (int64_t)((span + 7) / 8) * along * sp;
