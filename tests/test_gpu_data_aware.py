@@ -604,14 +604,15 @@ def test_hinv_full_size_property():
     assert float(R.abs().max()) < 2e-4, float(R.abs().max())
 
 
+@pytest.mark.parametrize("K", [2304, 12296])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_hessian_item_list_kernel(dtype):
-    """nncf_amd_hessian_accumulate_list: the MFMA kernel walks a list of separately allocated, ragged calibration
-    items (token counts that are not multiples of its 32-token stage, a 1-token item, > 128 items = two launches)
-    against the fp64 sum, through the C ABI and through HessianAccumulator (which no longer concatenates)."""
+def test_hessian_item_list_kernel(dtype, K):
+    """nncf_amd_hessian_accumulate_list: the MFMA kernels walk a list of separately allocated, ragged calibration
+    items (token counts that are not multiples of their 32-token stage, a 1-token item, > 128 items = two launches)
+    against the fp64 sum, through the C ABI and through HessianAccumulator (which no longer concatenates).
+    K = 2304: k_syrk16b; K = 12296 (49 tiles across, the last one ragged): the list form of k_gemm16t."""
     import ctypes
     from nncf_amd import _lib, gptq as G
-    K = 2304
     torch.manual_seed(4)
     toks = [37, 1, 64, 100, 33] * 27  # 135 items
     xs = [torch.randn(t, K, device="cuda").to(dtype) for t in toks]
