@@ -1013,7 +1013,7 @@ static int launch_syrk16b_list(float* h, const wc::SyrkItems& items, int x_dtype
     // against 512 + spills) holds 1.30 PFLOP/s on a 73728 x 28672 bf16 chunk (46.7 ms; the whole accumulate call with
     // its mirror pass 52.4 against 53.2 ms through k_syrk16b, a Llama-3-70B GPTQ layer 455 -> 452 ms); at K = 8192 (528
     // pairs: rounds of blocks that do not fill) k_syrk16b stays ahead (14.1 against 15.0 ms).
-    static const int64_t list_min_tiles = [] { const char* e = getenv("NNCF_AMD_SYRK_LIST_TILES"); return e ? atoll(e) : 48ll; }();
+    static const int64_t list_min_tiles = [] { const char* e = getenv("NNCF_AMD_SYRK_LIST_TILES"); return e ? atoll(e) : 48ll; }();  // developer knob
     if (nt >= list_min_tiles) {
         static OncePerDevice attr_list;
         if (attr_list.first_on_device() != 0) {
@@ -1263,8 +1263,14 @@ extern "C" int nncf_amd_gemm_bf16_tn_acc(float* c, int64_t ldc, const void* p, i
     // >= 2 rounds of blocks over the 256 CUs where the contraction is long enough to split (>= 64 stages per block on
     // average; a triangular product has about half the tile x stage work of the full one)
     const int64_t work_tiles = tri == 0 ? tiles : (tiles + 1) / 2;
+    // (developer knobs; measured: 1024 / 2048 / 4096 blocks wanted or 128 stages at least are all slower on the GPTQ
+    // layer's products than 512 and 64)
     static const int64_t want_blocks = [] { const char* e = getenv("NNCF_AMD_GEMM_BLOCKS"); return e ? atoll(e) : 512ll; }();
     static const int64_t min_stages = [] { const char* e = getenv("NNCF_AMD_GEMM_MINST"); return e ? atoll(e) : 64ll; }();
+    if (want_blocks < 1 || min_stages < 1) {
+        set_error("gemm_bf16_tn_acc: NNCF_AMD_GEMM_BLOCKS / NNCF_AMD_GEMM_MINST must be positive");
+        return NNCF_AMD_ERR_BAD_ARG;
+    }
     int64_t sp = work_tiles >= want_blocks ? 1 : (want_blocks + work_tiles - 1) / work_tiles;
     const int64_t maxsp = (stages + min_stages - 1) / min_stages;
     if (sp > maxsp) sp = maxsp;
