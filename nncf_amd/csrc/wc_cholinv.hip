@@ -217,7 +217,17 @@ __device__ __forceinline__ void cholinv_panel(float (&a)[CR][CR], float (&x)[CR]
             rows[(P * 16 + ti) * CLD + kk * 16 + tk] = sacc;
         }
         __syncthreads();
-        // (e)
+        // (e) the L rows of this thread's own rows, read once for both updates
+        float li[CR][PB];
+#pragma unroll
+        for (int ii = P + 1; ii < CR; ++ii) {
+            const float4* src = (const float4*)(lp + (ii * 16 + ti) * PP);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 v = src[c];
+                li[ii][4 * c] = v.x, li[ii][4 * c + 1] = v.y, li[ii][4 * c + 2] = v.z, li[ii][4 * c + 3] = v.w;
+            }
+        }
 #pragma unroll
         for (int kk = P + 1; kk < CR; ++kk) {
             float lk[PB];
@@ -228,16 +238,9 @@ __device__ __forceinline__ void cholinv_panel(float (&a)[CR][CR], float (&x)[CR]
             }
 #pragma unroll
             for (int ii = kk; ii < CR; ++ii) {
-                const float4* src = (const float4*)(lp + (ii * 16 + ti) * PP);
                 float sacc = 0.0f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float4 v = src[c];
-                    sacc = __builtin_fmaf(v.x, lk[4 * c], sacc);
-                    sacc = __builtin_fmaf(v.y, lk[4 * c + 1], sacc);
-                    sacc = __builtin_fmaf(v.z, lk[4 * c + 2], sacc);
-                    sacc = __builtin_fmaf(v.w, lk[4 * c + 3], sacc);
-                }
+                for (int j = 0; j < PB; ++j) sacc = __builtin_fmaf(li[ii][j], lk[j], sacc);
                 a[ii][kk] -= sacc;
             }
         }
@@ -248,16 +251,9 @@ __device__ __forceinline__ void cholinv_panel(float (&a)[CR][CR], float (&x)[CR]
             for (int j = 0; j < PB; ++j) xr[j] = rows[(P * 16 + j) * CLD + kk * 16 + tk];
 #pragma unroll
             for (int ii = P + 1; ii < CR; ++ii) {
-                const float4* src = (const float4*)(lp + (ii * 16 + ti) * PP);
                 float sacc = 0.0f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float4 v = src[c];
-                    sacc = __builtin_fmaf(v.x, xr[4 * c], sacc);
-                    sacc = __builtin_fmaf(v.y, xr[4 * c + 1], sacc);
-                    sacc = __builtin_fmaf(v.z, xr[4 * c + 2], sacc);
-                    sacc = __builtin_fmaf(v.w, xr[4 * c + 3], sacc);
-                }
+                for (int j = 0; j < PB; ++j) sacc = __builtin_fmaf(li[ii][j], xr[j], sacc);
                 x[ii][kk] -= sacc;
             }
         }
